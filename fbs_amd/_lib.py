@@ -1,0 +1,122 @@
+"""ctypes binding of libfbsmi (include/fbsmi.h) -- the only way fbs_amd reaches the GPU kernels.
+
+There is no CPU fallback: if the shared library is missing or a call fails, a ``RuntimeError`` is
+raised.  ``build()`` compiles the HIP sources in-tree for gfx950 with hipcc.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = [os.path.join(_HERE, "csrc", n) for n in ("fbsmi_prims.hip", "fbsmi_lg.hip", "fbsmi_sde.hip")]
+_DEPS = _SRC + [os.path.join(_HERE, "csrc", "fbsmi_device.h"), os.path.join(_HERE, "csrc", "fbsmi_host.h"),
+                os.path.join(_HERE, "..", "include", "fbsmi.h"), os.path.join(_HERE, "..", "include", "fbsmi_math.h")]
+LIB_PATH = os.path.join(_HERE, "lib", "libfbsmi.so")
+
+# -ffp-contract=off is part of the numeric specification (include/fbsmi_math.h)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wno-unused-value", "-Wno-pass-failed"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libfbsmi")
+
+
+def build(force: bool = False) -> str:
+    """Compile libfbsmi.so for gfx950 if it is missing or older than its sources."""
+    have_src = all(os.path.exists(p) for p in _DEPS)
+    stale = not os.path.exists(LIB_PATH)
+    if have_src and not stale:
+        t = os.path.getmtime(LIB_PATH)
+        stale = any(os.path.getmtime(p) > t for p in _DEPS)
+    if force or stale:
+        if not have_src:
+            raise RuntimeError("libfbsmi sources missing and no prebuilt library at " + LIB_PATH)
+        os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + _SRC
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class LGModelStruct(C.Structure):
+    _fields_ = [("du", C.c_int32), ("dv", C.c_int32), ("T", C.c_int32), ("dt", C.c_float),
+                ("G", C.c_void_p), ("g", C.c_void_p), ("sd", C.c_void_p), ("lognorm", C.c_void_p),
+                ("F", C.c_void_p), ("sqQ", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every int-returning entry is status-checked by call()
+_vp, _i32, _i64, _u32, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
+SIGNATURES = {
+    "fbsmi_abi_version": (C.c_int, []),
+    "fbsmi_last_error": (C.c_char_p, []),
+    "fbsmi_key_split": (None, [_u32, _u32, C.c_int, C.POINTER(C.c_uint32)]),
+    "fbsmi_random_bits": (C.c_int, [_u32, _u32, _i64, _vp, _vp]),
+    "fbsmi_uniform": (C.c_int, [_u32, _u32, _i64, _vp, _vp]),
+    "fbsmi_normal": (C.c_int, [_u32, _u32, _i64, _vp, _vp]),
+    "fbsmi_randint": (C.c_int, [_u32, _u32, _i64, _i32, _i32, _vp, _vp]),
+    "fbsmi_math_map": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp]),
+    "fbsmi_workspace_bytes": (C.c_size_t, [_i64]),
+    "fbsmi_cumsum": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "fbsmi_sum": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "fbsmi_logsumexp": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "fbsmi_normalise": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp, _vp]),
+    "fbsmi_searchsorted": (C.c_int, [_vp, _i32, _vp, _i64, _vp, _vp]),
+    "fbsmi_resample": (C.c_int, [C.c_int, _vp, _u32, _u32, _i32, _vp, _vp, _vp]),
+    "fbsmi_cond_resample": (C.c_int, [C.c_int, _u32, _u32, _vp, _i32, _i32, C.c_int, _i32, _vp, _vp, _vp]),
+    "fbsmi_categorical": (C.c_int, [_u32, _u32, _vp, _i32, _vp, _vp, _vp]),
+    "fbsmi_force_move": (C.c_int, [_u32, _u32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "fbsmi_gather_rows": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "fbsmi_set_row": (C.c_int, [_vp, _i64, _vp, _i64, _vp]),
+    "fbsmi_backtrace": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "fbsmi_linear_path": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
+    "fbsmi_affine_em_path": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, C.c_int, _vp, _vp]),
+    "fbsmi_lg_transition_sampler": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _u32, _u32, _i64, _vp, _vp]),
+    "fbsmi_lg_likelihood_logpdf": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "fbsmi_lg_transition_logpdf": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "fbsmi_lg_sweep_create": (C.c_int, [C.POINTER(LGModelStruct), _i32, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "fbsmi_lg_sweep_destroy": (None, [_vp]),
+    "fbsmi_lg_gibbs_sweep": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "fbsmi_lg_gibbs_chain": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_int, _vp]),
+    "fbsmi_lg_sweep_view": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(_i64), _vp]),
+    "fbsmi_lg_sweep_profile": (C.c_int, [_vp, C.c_int]),
+    "fbsmi_lg_sweep_kernel_us": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libfbsmi.so (building it first when the sources are newer)."""
+    global _lib
+    if _lib is None:
+        path = build()
+        try:
+            L = C.CDLL(path)
+        except OSError as e:  # no silent fallback
+            raise RuntimeError(f"cannot load the HIP extension {path}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if L.fbsmi_abi_version() != 1:
+            raise RuntimeError("libfbsmi ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def call(name: str, *args):
+    """Call an int-status entry point; raise RuntimeError with fbsmi_last_error() on failure."""
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        msg = L.fbsmi_last_error().decode("utf-8", "replace")
+        if rc == -3:
+            raise NotImplementedError(msg)
+        raise RuntimeError(f"{name} failed ({rc}): {msg}")
+    return rc

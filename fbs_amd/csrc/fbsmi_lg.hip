@@ -1,0 +1,949 @@
+// fbsmi_lg.hip -- the fused linear-Gaussian Gibbs sweep: gibbs_kernel (fbs/samplers/gibbs.py:68-168)
+// -> csmc.forward_pass (fbs/samplers/csmc/csmc.py:80-164) with conditional killing resampling
+// (fbs/samplers/csmc/resamplings.py:40-88), force_move (gibbs.py:171-214), the forward noising
+// sampler (fbs/sdes/linear.py:190-221) and the three model closures of
+// experiments/toy/gp_gibbs.py:120-135 folded in, entirely on the device.
+//
+// One SMC step has four grid-wide dependency levels, each a kernel (kernel boundaries are the
+// cheapest grid-wide synchronisation on MI355X, ~1.5 us):
+//
+//   norm  : lse from the previous kernel's per-workgroup partials; w = exp(lw - lse);
+//           w_max = exp(max lw - lse) (fbsmi_expf is monotone, so this IS max_i w_i);
+//           per-workgroup tree sums of w and of J_prob                        [csmc.py:146,139]
+//   cdf   : canonical-tree cumsum of w and of J_prob (J_prob[i*] needs the total first)
+//                                                                        [resamplings.py:74-84]
+//   prop  : J ~ Cat(J_prob); per slot: rotate by j*-J, kill test, Cat(w) draw for killed slots,
+//           pin, gather the ancestor, Euler-Maruyama step, pin the reference, Gaussian
+//           log-weight, per-workgroup max                      [resamplings.py:71-86, csmc.py:140-145]
+//   sumexp: per-workgroup tree sums of exp(lw - max)                          [csmc.py:289]
+//
+// Particle state is structure-of-arrays u[r][p] so that every per-slot access is coalesced.
+// A whole sweep (4T + ~10 launches) is captured once into a hipGraph and replayed.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fbsmi.h"
+#include "fbsmi_device.h"
+#include "fbsmi_host.h"
+
+namespace fbsmi {
+
+constexpr int kMaxNbSweep = 1024;  // workgroup partials one in-kernel top tree handles
+constexpr int kNumProfKernels = 4; // norm, cdf, prop, sumexp
+
+struct LgDev {
+    int N;           // rows of the particle system (nparticles, +1 when explicit_final)
+    int nparticles;
+    int du, dv, D, T;
+    int nb;          // workgroups of every tile kernel
+    int levels;      // bisection levels for N
+    int eb, ef, store;
+    float dt;
+    float lw_init;   // -log(nparticles)
+    const float *G, *g, *sd, *lognorm, *F, *sqQ;
+    // per-sweep inputs (internal copies)
+    uint32_t* key;   // [2]
+    float* x0;       // [du]
+    float* y0;       // [dv]
+    int32_t* bs;     // [T+1]
+    // derived per sweep
+    uint32_t* keytab;  // [T][8]: key_1, key_2, key_3 of the killing resampler, key_transition
+    uint32_t* misc;    // [16]: 0 key_fwd, 2 key_init, 4 key_x0(force_move), 6 key_us, 8 key_bs, 10 key_bwd
+    float* xi1;        // [T][D] noise of the first forward path
+    float* xi2;        // [T][D] noise of the second forward path (us_star_next)
+    float* path;       // [T+1][D]
+    float* us_star;    // [T+1][du]
+    float* vs;         // [T+1][dv]
+    // state
+    float* u0;         // [du][N]
+    float* u1;
+    float* lw;         // [N] unnormalised log-weights
+    float* lwn;        // [N] normalised log-weights of the last normalise
+    float* w;          // [N]
+    float* cdf;        // [N]
+    float* cdfJ;       // [N]
+    float *bmax, *bsumexp, *bsumw, *bsumJ;  // [nb]
+    float* scal;       // [16]: 0 lse, 1 w_max
+    int32_t* As;       // [T][N] or null
+    float* uss;        // [T+1][N][du] or null
+    float* lwss;       // [T+1][N] or null
+    float* usT;        // [N][du] row-major copy of the final particles
+    // outputs (internal)
+    float* x0n;        // [du]
+    float* usn;        // [T+1][du]
+    int32_t* bsn;      // [T+1]
+    uint8_t* acc;      // [T+1]
+    // chain bookkeeping
+    float** x0s_slot;  // device slot holding the x0s pointer (or null)
+    int32_t* counter;  // device sweep counter
+};
+
+// ------------------------------------------------------------------------------------------
+// sweep prologue: key derivation, forward noising path
+// ------------------------------------------------------------------------------------------
+// gibbs.py:126,147 ; csmc.py:65,150,157,136 ; resamplings.py:66
+__global__ void __launch_bounds__(kBlock) k_lg_keys(LgDev d, int chain) {
+    __shared__ uint32_t sk[4];
+    if (threadIdx.x == 0) {
+        uint32_t k0 = d.key[0], k1 = d.key[1];
+        if (chain) {  // key, subkey = split(key)
+            uint32_t a0, a1, b0, b1;
+            split_at(k0, k1, 2, 0, a0, a1);
+            split_at(k0, k1, 2, 1, b0, b1);
+            d.key[0] = a0;
+            d.key[1] = a1;
+            k0 = b0;
+            k1 = b1;
+        }
+        uint32_t f0, f1, c0, c1;
+        split_at(k0, k1, 3, 0, f0, f1);  // key_fwd
+        split_at(k0, k1, 3, 1, c0, c1);  // key_csmc  (key_bridge unused: marg_y=False)
+        uint32_t cf0, cf1;
+        if (d.eb) {
+            split_at(c0, c1, 4, 0, cf0, cf1);                    // key_csmc_fwd
+            split_at(c0, c1, 4, 1, d.misc[4], d.misc[5]);        // key_csmc_x0
+            split_at(c0, c1, 4, 2, d.misc[6], d.misc[7]);        // key_csmc_bwd_us
+            split_at(c0, c1, 4, 3, d.misc[8], d.misc[9]);        // key_csmc_bwd_bs
+        } else {
+            split_at(c0, c1, 2, 0, cf0, cf1);                    // key_fwd of csmc_kernel
+            split_at(c0, c1, 2, 1, d.misc[10], d.misc[11]);      // key_bwd
+            d.misc[6] = 0; d.misc[7] = 0;
+        }
+        d.misc[0] = f0;
+        d.misc[1] = f1;
+        split_at(cf0, cf1, 2, 0, d.misc[2], d.misc[3]);          // key_init
+        split_at(cf0, cf1, 2, 1, sk[0], sk[1]);                  // key_scan
+    }
+    __syncthreads();
+    const uint32_t s0 = sk[0], s1 = sk[1];
+    for (int s = threadIdx.x; s < d.T; s += kBlock) {
+        uint32_t q0, q1, r0, r1;
+        split_at(s0, s1, d.T, s, q0, q1);  // keys[s]
+        uint32_t* kt = d.keytab + 8 * s;
+        split_at(q0, q1, 2, 0, r0, r1);    // key_resampling
+        split_at(q0, q1, 2, 1, kt[6], kt[7]);  // key_transition
+        split_at(r0, r1, 3, 0, kt[0], kt[1]);
+        split_at(r0, r1, 3, 1, kt[2], kt[3]);
+        split_at(r0, r1, 3, 2, kt[4], kt[5]);
+    }
+}
+
+// normal(key, (T, D)) for both forward paths (linear.py:220)
+__global__ void k_lg_noise(LgDev d) {
+    const uint64_t n = (uint64_t)d.T * d.D;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        d.xi1[i] = normal_at(d.misc[0], d.misc[1], n, i);
+        if (d.eb) d.xi2[i] = normal_at(d.misc[6], d.misc[7], n, i);
+    }
+}
+
+// x_{k+1} = F_k x_k + sqrt(Q_k) xi_k (linear.py:211-221), one thread per coordinate; then the
+// time reversal and unpack of gibbs.py:128-130.  which = 0: from (x0, y0) -> us_star, vs;
+// which = 1: from (x0n, y0) -> usn (gibbs.py:155), bs_next, acc (gibbs.py:156,168).
+__global__ void k_lg_path(LgDev d, int which) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* xi = which ? d.xi2 : d.xi1;
+    if (c < d.D) {
+        float x = c < d.du ? (which ? d.x0n[c] : d.x0[c]) : d.y0[c - d.du];
+        for (int k = 0; k <= d.T; ++k) {
+            const int rk = d.T - k;  // reversed index
+            if (c < d.du) {
+                if (which) d.usn[(size_t)rk * d.du + c] = x;
+                else d.us_star[(size_t)rk * d.du + c] = x;
+            } else if (!which) {
+                d.vs[(size_t)rk * d.dv + (c - d.du)] = x;
+            }
+            if (k < d.T) x = d.F[k] * x + d.sqQ[k] * xi[(size_t)k * d.D + c];
+        }
+    }
+    if (which) {
+        for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= d.T; k += gridDim.x * blockDim.x) {
+            const int32_t b = randint_at(d.misc[8], d.misc[9], (uint64_t)d.T + 1, (uint64_t)k, 0, d.nparticles);
+            d.acc[k] = b != d.bs[k];
+            d.bsn[k] = b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// model closures
+// ------------------------------------------------------------------------------------------
+template <int DMAX>
+struct StepTables {
+    const float* G;
+    const float* g;
+    float sd, sd2, lognorm, dt;
+    int du, dv, D;
+};
+
+template <int DMAX>
+__device__ __forceinline__ StepTables<DMAX> step_tables(const LgDev& d, int s) {
+    StepTables<DMAX> t;
+    t.G = d.G + (size_t)s * d.D * d.D;
+    t.g = d.g + (size_t)s * d.D;
+    t.sd = d.sd[s];
+    t.sd2 = t.sd * t.sd;
+    t.lognorm = d.lognorm[s];
+    t.dt = d.dt;
+    t.du = d.du;
+    t.dv = d.dv;
+    t.D = d.D;
+    return t;
+}
+
+// drift_r = g_r + sum_c G_rc z_c, a c-ordered fma chain started at g_r, z = (u, v_prev)
+template <int DMAX>
+__device__ __forceinline__ float drift_row(const StepTables<DMAX>& t, int r, const float (&u)[DMAX],
+                                           const float* __restrict__ v_prev) {
+    const float* Gr = t.G + (size_t)r * t.D;
+    float acc = t.g[r];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+        if (c < t.du) acc = fbsmi_fmaf(Gr[c], u[c], acc);
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+        if (c < t.dv) acc = fbsmi_fmaf(Gr[t.du + c], v_prev[c], acc);
+    return acc;
+}
+
+__device__ __forceinline__ float norm_logpdf(float x, float loc, float sd2, float lognorm) {
+    const float dlt = x - loc;
+    return (lognorm + (dlt * dlt) / sd2) / -2.0f;
+}
+
+// likelihood_logpdf(v, u_prev, v_prev, t_prev): gp_gibbs.py:131-135
+template <int DMAX>
+__device__ __forceinline__ float lg_loglik(const StepTables<DMAX>& t, const float (&u)[DMAX],
+                                           const float* __restrict__ v, const float* __restrict__ v_prev) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) {
+        if (r < t.dv) {
+            const float dr = drift_row<DMAX>(t, t.du + r, u, v_prev);
+            const float cond_m = v_prev[r] + dr * t.dt;
+            const float lp = norm_logpdf(v[r], cond_m, t.sd2, t.lognorm);
+            acc = r == 0 ? lp : acc + lp;
+        }
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// init: csmc.py:150-155 with the init_sampler / init_likelihood_logpdf of gibbs.py:132-144
+// ------------------------------------------------------------------------------------------
+template <int ITEMS, int DMAX>
+__global__ void __launch_bounds__(kBlock) k_lg_init(LgDev d) {
+    __shared__ float s4[4];
+    const StepTables<DMAX> t = step_tables<DMAX>(d, 0);
+    const int b0 = d.bs[0];
+    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    float mloc = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int p = base + i;
+        if (p < d.N) {
+            float u[DMAX];
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) {
+                if (r < d.du) {
+                    float v = d.us_star[r];
+                    if (d.ef && p != b0)
+                        v = normal_at(d.misc[2], d.misc[3], (uint64_t)d.N * d.du, (uint64_t)p * d.du + r);
+                    u[r] = v;
+                    d.u0[(size_t)r * d.N + p] = v;
+                    if (d.uss) d.uss[(size_t)p * d.du + r] = v;
+                } else {
+                    u[r] = 0.0f;
+                }
+            }
+            // gibbs.py:136-137: likelihood_logpdf(vs[0], u0s, vs[1], ts[0]) ; :143-144: -log(nparticles)
+            const float l = d.ef ? lg_loglik<DMAX>(t, u, d.vs, d.vs + d.dv) : d.lw_init;
+            d.lw[p] = l;
+            mloc = fmaxf(mloc, l);
+        }
+    }
+    mloc = block_max(mloc, s4);
+    if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
+}
+
+// ------------------------------------------------------------------------------------------
+// sumexp: per-workgroup tree sums of exp(lw - amax)
+// ------------------------------------------------------------------------------------------
+template <int ITEMS>
+__global__ void __launch_bounds__(kBlock) k_lg_sumexp(LgDev d) {
+    __shared__ float s4[4];
+    const float M = finite_or_zero(top_max(d.bmax, d.nb, s4));
+    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    float x[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) x[i] = base + i < d.N ? fbsmi_expf(d.lw[base + i] - M) : 0.0f;
+    TreePath path;
+    const float tot = block_upsweep(chunk_total<ITEMS>(x), path, s4);
+    if (threadIdx.x == 0) d.bsumexp[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------------------------------
+// norm.  MODE 0: step s (J_prob partials for the conditional killing of step s);
+//        MODE 1: final, explicit backward (force_move rest-weight partials, gibbs.py:200-205);
+//        MODE 2: final, backward scanning (partials of w only).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float jprob_at(float w, float w_max, int N) { return (1.0f - w / w_max) / (float)N; }
+
+__device__ __forceinline__ float fm_rest_at(float w, float w_k, bool is_k, int N) {
+    if (w_k < 1.0f) return (is_k ? 0.0f : w) / (1.0f - w_k);
+    return (float)(1.0 / (double)N);
+}
+
+template <int ITEMS, int MODE>
+__global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev d, int s) {
+    __shared__ float s4[4];
+    __shared__ float s_top[kMaxNbSweep];
+    const float Mraw = top_max(d.bmax, d.nb, s4);
+    const float M = finite_or_zero(Mraw);
+    float S, dP, dE;
+    top_tree(d.bsumexp, d.nb, 0, s_top, S, dP, dE);
+    const float lse = fbsmi_logf(S) + M;
+    const float w_max = fbsmi_expf(Mraw - lse);
+    const int i_ref = d.bs[MODE == 0 ? s : d.T];
+    const float w_k = MODE == 1 ? fbsmi_expf(d.lw[i_ref] - lse) : 0.0f;
+    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    float xw[ITEMS], xj[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int e = base + i;
+        xw[i] = 0.0f;
+        xj[i] = 0.0f;
+        if (e < d.N) {
+            const float ln = d.lw[e] - lse;
+            const float w = fbsmi_expf(ln);
+            d.w[e] = w;
+            d.lwn[e] = ln;
+            if (d.lwss) d.lwss[(size_t)s * d.N + e] = ln;
+            xw[i] = w;
+            if (MODE == 0) xj[i] = e == i_ref ? 0.0f : jprob_at(w, w_max, d.N);
+            if (MODE == 1) xj[i] = fm_rest_at(w, w_k, e == i_ref, d.N);
+        }
+    }
+    TreePath path;
+    if (MODE != 1) {
+        const float tw = block_upsweep(chunk_total<ITEMS>(xw), path, s4);
+        if (threadIdx.x == 0) d.bsumw[blockIdx.x] = tw;
+    }
+    if (MODE != 2) {
+        const float tj = block_upsweep(chunk_total<ITEMS>(xj), path, s4);
+        if (threadIdx.x == 0) d.bsumJ[blockIdx.x] = tj;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d.scal[0] = lse;
+        d.scal[1] = w_max;
+        d.scal[2] = w_k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// cdf.  MODE 0: cumsum(w) -> cdf and cumsum(J_prob) -> cdfJ; MODE 1: cumsum(rest) -> cdf;
+//       MODE 2: cumsum(w) -> cdf.
+// ------------------------------------------------------------------------------------------
+template <int ITEMS, int MODE>
+__global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev d, int s) {
+    __shared__ float s4[4];
+    __shared__ float s_top[kMaxNbSweep];
+    constexpr int TILE = kBlock * ITEMS;
+    const float w_max = d.scal[1];
+    const float w_k = d.scal[2];
+    const int i_ref = d.bs[MODE == 0 ? s : d.T];
+    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    TreePath path;
+    float root, P, E;
+    if (MODE == 0 || MODE == 2) {
+        top_tree(d.bsumw, d.nb, blockIdx.x, s_top, root, P, E);
+        float x[ITEMS], c[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) x[i] = base + i < d.N ? d.w[base + i] : 0.0f;
+        block_upsweep(chunk_total<ITEMS>(x), path, s4);
+        block_descend(P, E, path);
+        chunk_scan<ITEMS>(x, P, E, c);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (base + i < d.N) d.cdf[base + i] = c[i];
+    }
+    if (MODE == 0) {
+        // J_prob[i*] = max(1 - sum(J_prob with [i*] = 0), 0)   (resamplings.py:80-82)
+        float SJ, dP, dE;
+        top_tree(d.bsumJ, d.nb, 0, s_top, SJ, dP, dE);
+        const float Ji = fmaxf(1.0f - SJ, 0.0f);
+        // the tile that holds i* has a new tree sum: every workgroup rebuilds it
+        const int b_ref = i_ref / TILE;
+        const int rbase = b_ref * TILE + threadIdx.x * ITEMS;
+        float x[ITEMS], c[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int e = rbase + i;
+            x[i] = e < d.N ? (e == i_ref ? Ji : jprob_at(d.w[e], w_max, d.N)) : 0.0f;
+        }
+        const float newsum = block_upsweep(chunk_total<ITEMS>(x), path, s4);
+        top_tree(d.bsumJ, d.nb, blockIdx.x, s_top, root, P, E, b_ref, newsum);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int e = base + i;
+            x[i] = e < d.N ? (e == i_ref ? Ji : jprob_at(d.w[e], w_max, d.N)) : 0.0f;
+        }
+        block_upsweep(chunk_total<ITEMS>(x), path, s4);
+        block_descend(P, E, path);
+        chunk_scan<ITEMS>(x, P, E, c);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (base + i < d.N) d.cdfJ[base + i] = c[i];
+    }
+    if (MODE == 1) {
+        top_tree(d.bsumJ, d.nb, blockIdx.x, s_top, root, P, E);
+        float x[ITEMS], c[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int e = base + i;
+            x[i] = e < d.N ? fm_rest_at(d.w[e], w_k, e == i_ref, d.N) : 0.0f;
+        }
+        block_upsweep(chunk_total<ITEMS>(x), path, s4);
+        block_descend(P, E, path);
+        chunk_scan<ITEMS>(x, P, E, c);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (base + i < d.N) d.cdf[base + i] = c[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// prop: resample (killing, conditional) + gather + Euler-Maruyama + pin + log-weight
+// ------------------------------------------------------------------------------------------
+template <int ITEMS, int DMAX>
+__global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev d, int s) {
+    __shared__ float s4[4];
+    __shared__ int s_shift;
+    const int N = d.N;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5], t0 = kt[6], t1 = kt[7];
+    const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
+    if (threadIdx.x == 0) {
+        // J = choice(key_3, N, (), p=J_prob)  (resamplings.py:84); roll by j - J (:85)
+        const float u3 = uniform_at(c0, c1, 1, 0);
+        const int J = searchsorted_left(d.cdfJ, N, d.levels, d.cdfJ[N - 1] * (1.0f - u3));
+        int sh = (j_ref - J) % N;
+        if (sh < 0) sh += N;
+        s_shift = sh;
+    }
+    __syncthreads();
+    const int shift = s_shift;
+    const float last = d.cdf[N - 1];
+    const float w_max = d.scal[1];
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    const StepTables<DMAX> t = step_tables<DMAX>(d, s);
+    const float* v_prev = d.vs + (size_t)s * d.dv;
+    const float* v = d.vs + (size_t)(s + 1) * d.dv;
+    const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
+    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    float mloc = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int m = base + i;
+        if (m < N) {
+            int src = m - shift;
+            if (src < 0) src += N;
+            const float ws = d.w[src];
+            const float u1 = uniform_at(a0, a1, (uint64_t)N, (uint64_t)src);
+            int a = src;
+            if (u1 * w_max >= ws) {  // killed (resamplings.py:71): redraw from Cat(w) (:73-74)
+                const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)src);
+                a = searchsorted_left(d.cdf, N, d.levels, last * (1.0f - u2));
+            }
+            if (m == j_ref) a = i_ref;  // :86
+            if (d.As) d.As[(size_t)s * N + m] = a;
+            float u[DMAX];
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) u[r] = r < d.du ? up[(size_t)r * N + a] : 0.0f;
+            // transition_sampler (gp_gibbs.py:120-122) and the pin of csmc.py:143
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) {
+                if (r < d.du) {
+                    const float dr = drift_row<DMAX>(t, r, u, v_prev);
+                    const float xi = normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r);
+                    float x = (u[r] + dr * t.dt) + t.sd * xi;
+                    if (m == j_ref) x = ustar[r];
+                    un[(size_t)r * N + m] = x;
+                    if (d.uss) d.uss[((size_t)(s + 1) * N + m) * d.du + r] = x;
+                }
+            }
+            // likelihood_logpdf on the gathered particle (csmc.py:145)
+            const float l = lg_loglik<DMAX>(t, u, v, v_prev);
+            d.lw[m] = l;
+            mloc = fmaxf(mloc, l);
+        }
+    }
+    mloc = block_max(mloc, s4);
+    if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
+}
+
+// ------------------------------------------------------------------------------------------
+// sweep epilogue
+// ------------------------------------------------------------------------------------------
+// explicit backward (gibbs.py:152-154): force_move tail, x0 = uss[-1, idx]
+__global__ void k_lg_force_move(LgDev d) {
+    const float* uT = (d.T & 1) ? d.u1 : d.u0;
+    __shared__ int s_idx;
+    if (threadIdx.x == 0) {
+        const int N = d.N;
+        uint32_t p0, p1, q0, q1;
+        split_at(d.misc[4], d.misc[5], 2, 0, p0, p1);
+        split_at(d.misc[4], d.misc[5], 2, 1, q0, q1);
+        const int k = d.bs[d.T];
+        const float u1 = uniform_at(p0, p1, 1, 0);
+        const int i = searchsorted_left(d.cdf, N, d.levels, d.cdf[N - 1] * (1.0f - u1));
+        const float u = uniform_at(q0, q1, 1, 0);
+        const float temp = 1.0f - d.w[k];
+        const bool accept = u * (1.0f - d.w[i]) < temp;
+        s_idx = accept ? i : k;
+    }
+    __syncthreads();
+    const int idx = s_idx;
+    for (int r = threadIdx.x; r < d.du; r += blockDim.x) d.x0n[r] = uT[(size_t)r * d.N + idx];
+}
+
+// backward scanning (csmc.py:230-270): B_T ~ Cat(w_T), B_{k-1} = A_k[B_k], x_k = uss[k, B_k]
+__global__ void k_lg_backscan(LgDev d) {
+    __shared__ int s_B[1];
+    const int N = d.N;
+    if (threadIdx.x == 0) {
+        const float u = uniform_at(d.misc[10], d.misc[11], 1, 0);
+        int B = searchsorted_left(d.cdf, N, d.levels, d.cdf[N - 1] * (1.0f - u));
+        d.bsn[d.T] = B;
+        for (int k = d.T; k >= 1; --k) {
+            B = d.As[(size_t)(k - 1) * N + B];
+            d.bsn[k - 1] = B;
+        }
+        s_B[0] = 0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < (d.T + 1) * d.du; e += blockDim.x) {
+        const int k = e / d.du, r = e - k * d.du;
+        const float x = d.uss[((size_t)k * N + d.bsn[k]) * d.du + r];
+        d.usn[e] = x;
+        if (k == d.T) d.x0n[r] = x;
+    }
+    for (int k = threadIdx.x; k <= d.T; k += blockDim.x) d.acc[k] = d.bsn[k] != d.bs[k];
+}
+
+// row-major copy of the final particles (parity view)
+__global__ void k_lg_export(LgDev d) {
+    const float* uT = (d.T & 1) ? d.u1 : d.u0;
+    const size_t tot = (size_t)d.N * d.du;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = e / d.du, r = e - p * d.du;
+        d.usT[e] = uT[r * d.N + p];
+    }
+}
+
+// chain step: x0 <- x0_next, bs <- bs_next, x0s[counter++] = x0_next
+__global__ void k_lg_advance(LgDev d) {
+    const int c = *d.counter;
+    float* x0s = d.x0s_slot ? *d.x0s_slot : nullptr;
+    for (int r = threadIdx.x; r < d.du; r += blockDim.x) {
+        const float x = d.x0n[r];
+        d.x0[r] = x;
+        if (x0s) x0s[(size_t)c * d.du + r] = x;
+    }
+    for (int k = threadIdx.x; k <= d.T; k += blockDim.x) d.bs[k] = d.bsn[k];
+    __syncthreads();
+    if (threadIdx.x == 0) *d.counter = c + 1;
+}
+
+}  // namespace fbsmi
+
+using namespace fbsmi;
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct fbsmi_lg_sweep {
+    LgDev d{};
+    int items = 1, dmax = 2;
+    std::vector<void*> allocs;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipGraphExec_t graph_single = nullptr;  // one sweep, no chain bookkeeping
+    hipGraphExec_t graph_chain = nullptr;   // one sweep + key split + advance
+    bool profile = false;
+    std::vector<hipEvent_t> prof_ev[kNumProfKernels];  // pairs (start, stop)
+    double prof_us[kNumProfKernels] = {0, 0, 0, 0};
+    int64_t prof_n[kNumProfKernels] = {0, 0, 0, 0};
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(fbsmi_lg_sweep* s, T** p, size_t count) {
+    void* q = nullptr;
+    FBSMI_HIP_TRY(hipMalloc(&q, sizeof(T) * (count ? count : 1)));
+    FBSMI_HIP_TRY(hipMemset(q, 0, sizeof(T) * (count ? count : 1)));
+    s->allocs.push_back(q);
+    *p = (T*)q;
+    return 0;
+}
+
+#define LG_DISPATCH(s, ...)                                                                   \
+    do {                                                                                      \
+        if ((s)->items == 1) {                                                                \
+            constexpr int ITEMS = 1;                                                          \
+            if ((s)->dmax == 2) { constexpr int DMAX = 2; __VA_ARGS__; }                      \
+            else if ((s)->dmax == 4) { constexpr int DMAX = 4; __VA_ARGS__; }                 \
+            else { constexpr int DMAX = 16; __VA_ARGS__; }                                    \
+        } else if ((s)->items == 4) {                                                         \
+            constexpr int ITEMS = 4;                                                          \
+            if ((s)->dmax == 2) { constexpr int DMAX = 2; __VA_ARGS__; }                      \
+            else if ((s)->dmax == 4) { constexpr int DMAX = 4; __VA_ARGS__; }                 \
+            else { constexpr int DMAX = 16; __VA_ARGS__; }                                    \
+        } else {                                                                              \
+            constexpr int ITEMS = 16;                                                         \
+            if ((s)->dmax == 2) { constexpr int DMAX = 2; __VA_ARGS__; }                      \
+            else if ((s)->dmax == 4) { constexpr int DMAX = 4; __VA_ARGS__; }                 \
+            else { constexpr int DMAX = 16; __VA_ARGS__; }                                    \
+        }                                                                                     \
+    } while (0)
+
+struct ProfScope {
+    fbsmi_lg_sweep* s;
+    int which;
+    hipStream_t st;
+    ProfScope(fbsmi_lg_sweep* s_, int which_, hipStream_t st_) : s(s_), which(which_), st(st_) {
+        if (s->profile) {
+            hipEvent_t e;
+            hipEventCreate(&e);
+            hipEventRecord(e, st);
+            s->prof_ev[which].push_back(e);
+        }
+    }
+    ~ProfScope() {
+        if (s->profile) {
+            hipEvent_t e;
+            hipEventCreate(&e);
+            hipEventRecord(e, st);
+            s->prof_ev[which].push_back(e);
+        }
+    }
+};
+
+// the launch sequence of one sweep on stream st
+int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
+    const LgDev& d = s->d;
+    const int nb = d.nb;
+    k_lg_keys<<<1, kBlock, 0, st>>>(d, chain);
+    {
+        const int64_t n = (int64_t)d.T * d.D;
+        int g = (int)((n + 255) / 256);
+        g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+        k_lg_noise<<<g, 256, 0, st>>>(d);
+    }
+    const int gpath = (d.D + 63) / 64;
+    k_lg_path<<<gpath, 64, 0, st>>>(d, 0);
+    LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<nb, kBlock, 0, st>>>(d)));
+    for (int k = 0; k < d.T; ++k) {
+        {
+            ProfScope p(s, 3, st);
+            LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<nb, kBlock, 0, st>>>(d)));
+        }
+        {
+            ProfScope p(s, 0, st);
+            LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 0><<<nb, kBlock, 0, st>>>(d, k)));
+        }
+        {
+            ProfScope p(s, 1, st);
+            LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 0><<<nb, kBlock, 0, st>>>(d, k)));
+        }
+        {
+            ProfScope p(s, 2, st);
+            LG_DISPATCH(s, (k_lg_prop<ITEMS, DMAX><<<nb, kBlock, 0, st>>>(d, k)));
+        }
+    }
+    LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<nb, kBlock, 0, st>>>(d)));
+    if (d.eb) {
+        LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 1><<<nb, kBlock, 0, st>>>(d, d.T)));
+        LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 1><<<nb, kBlock, 0, st>>>(d, d.T)));
+        k_lg_force_move<<<1, 64, 0, st>>>(d);
+        k_lg_path<<<gpath > (d.T + 64) / 64 ? gpath : (d.T + 64) / 64, 64, 0, st>>>(d, 1);
+    } else {
+        LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 2><<<nb, kBlock, 0, st>>>(d, d.T)));
+        LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 2><<<nb, kBlock, 0, st>>>(d, d.T)));
+        k_lg_backscan<<<1, 256, 0, st>>>(d);
+    }
+    {
+        const int64_t n = (int64_t)d.N * d.du;
+        int g = (int)((n + 255) / 256);
+        g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+        k_lg_export<<<g, 256, 0, st>>>(d);
+    }
+    if (chain) k_lg_advance<<<1, 256, 0, st>>>(d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("sweep launch: ") + hipGetErrorString(e));
+    return FBSMI_OK;
+}
+
+int get_graph(fbsmi_lg_sweep* s, int chain, hipGraphExec_t* out) {
+    hipGraphExec_t& slot = chain ? s->graph_chain : s->graph_single;
+    if (!slot) {
+        hipGraph_t g = nullptr;
+        FBSMI_HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+        int rc = enqueue_sweep(s, s->stream, chain);
+        hipError_t e = hipStreamEndCapture(s->stream, &g);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        FBSMI_HIP_TRY(hipGraphInstantiate(&slot, g, nullptr, nullptr, 0));
+        FBSMI_HIP_TRY(hipGraphDestroy(g));
+    }
+    *out = slot;
+    return FBSMI_OK;
+}
+
+int run_sweep(fbsmi_lg_sweep* s, int chain, int use_graph) {
+    if (use_graph && !s->profile) {
+        hipGraphExec_t g;
+        int rc = get_graph(s, chain, &g);
+        if (rc) return rc;
+        FBSMI_HIP_TRY(hipGraphLaunch(g, s->stream));
+        return FBSMI_OK;
+    }
+    return enqueue_sweep(s, s->stream, chain);
+}
+
+int collect_profile(fbsmi_lg_sweep* s) {
+    if (!s->profile) return FBSMI_OK;
+    FBSMI_HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int w = 0; w < kNumProfKernels; ++w) {
+        auto& v = s->prof_ev[w];
+        for (size_t i = 0; i + 1 < v.size(); i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, v[i], v[i + 1]) == hipSuccess) {
+                s->prof_us[w] += (double)ms * 1000.0;
+                s->prof_n[w] += 1;
+            }
+        }
+        for (auto e : v) hipEventDestroy(e);
+        v.clear();
+    }
+    return FBSMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int explicit_backward, int explicit_final,
+                          int store_path, fbsmi_lg_sweep** out) {
+    if (!m || !out || nparticles < 1 || m->du < 1 || m->dv < 1 || m->T < 1)
+        return fail(FBSMI_ERR_ARG, "lg_sweep_create: bad arguments");
+    if (!m->G || !m->g || !m->sd || !m->lognorm || !m->F || !m->sqQ)
+        return fail(FBSMI_ERR_ARG, "lg_sweep_create: null model table");
+    const int D = m->du + m->dv;
+    if (m->du > 16 || m->dv > 16)
+        return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: du, dv > 16 need the tiled-drift kernel (not built yet)");
+    if (!explicit_backward && !store_path)
+        return fail(FBSMI_ERR_ARG, "lg_sweep_create: explicit_backward=0 needs store_path (As, uss)");
+    fbsmi_lg_sweep* s = new (std::nothrow) fbsmi_lg_sweep();
+    if (!s) return fail(FBSMI_ERR_ARG, "out of host memory");
+    LgDev& d = s->d;
+    d.nparticles = nparticles;
+    d.N = explicit_final ? nparticles + 1 : nparticles;
+    d.du = m->du;
+    d.dv = m->dv;
+    d.D = D;
+    d.T = m->T;
+    d.eb = explicit_backward ? 1 : 0;
+    d.ef = explicit_final ? 1 : 0;
+    d.store = store_path ? 1 : 0;
+    d.dt = m->dt;
+    d.lw_init = (float)(-log((double)nparticles));
+    d.G = m->G; d.g = m->g; d.sd = m->sd; d.lognorm = m->lognorm; d.F = m->F; d.sqQ = m->sqQ;
+    d.levels = bisect_levels(d.N);
+    s->items = d.N <= (1 << 17) ? 1 : (d.N <= (1 << 20) ? 4 : 16);
+    const int maxd = m->du > m->dv ? m->du : m->dv;
+    s->dmax = maxd <= 2 ? 2 : (maxd <= 4 ? 4 : 16);
+    const int tile = kBlock * s->items;
+    d.nb = (d.N + tile - 1) / tile;
+    if (d.nb > kMaxNbSweep) {
+        delete s;
+        return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: more than 4M particles per device not supported yet");
+    }
+    if (store_path) {
+        const double bytes = ((double)d.T * d.N * 4.0) + ((double)(d.T + 1) * d.N * (d.du + 1) * 4.0);
+        if (bytes > 200e9) {
+            delete s;
+            return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: path storage (T,N,du) does not fit device memory");
+        }
+    }
+    const size_t N = d.N, T = d.T;
+    int rc = 0;
+    rc |= dev_alloc(s, &d.key, 2);
+    rc |= dev_alloc(s, &d.x0, d.du);
+    rc |= dev_alloc(s, &d.y0, d.dv);
+    rc |= dev_alloc(s, &d.bs, T + 1);
+    rc |= dev_alloc(s, &d.keytab, 8 * T);
+    rc |= dev_alloc(s, &d.misc, 16);
+    rc |= dev_alloc(s, &d.xi1, T * D);
+    rc |= dev_alloc(s, &d.xi2, T * D);
+    rc |= dev_alloc(s, &d.path, (T + 1) * D);
+    rc |= dev_alloc(s, &d.us_star, (T + 1) * d.du);
+    rc |= dev_alloc(s, &d.vs, (T + 1) * d.dv);
+    rc |= dev_alloc(s, &d.u0, N * d.du);
+    rc |= dev_alloc(s, &d.u1, N * d.du);
+    rc |= dev_alloc(s, &d.lw, N);
+    rc |= dev_alloc(s, &d.lwn, N);
+    rc |= dev_alloc(s, &d.w, N);
+    rc |= dev_alloc(s, &d.cdf, N);
+    rc |= dev_alloc(s, &d.cdfJ, N);
+    rc |= dev_alloc(s, &d.bmax, d.nb);
+    rc |= dev_alloc(s, &d.bsumexp, d.nb);
+    rc |= dev_alloc(s, &d.bsumw, d.nb);
+    rc |= dev_alloc(s, &d.bsumJ, d.nb);
+    rc |= dev_alloc(s, &d.scal, 16);
+    rc |= dev_alloc(s, &d.usT, N * d.du);
+    rc |= dev_alloc(s, &d.x0n, d.du);
+    rc |= dev_alloc(s, &d.usn, (T + 1) * d.du);
+    rc |= dev_alloc(s, &d.bsn, T + 1);
+    rc |= dev_alloc(s, &d.acc, T + 1);
+    rc |= dev_alloc(s, &d.x0s_slot, 1);
+    rc |= dev_alloc(s, &d.counter, 1);
+    if (store_path) {
+        rc |= dev_alloc(s, &d.As, T * N);
+        rc |= dev_alloc(s, &d.uss, (T + 1) * N * d.du);
+        rc |= dev_alloc(s, &d.lwss, (T + 1) * N);
+    }
+    if (rc) {
+        fbsmi_lg_sweep_destroy(s);
+        return FBSMI_ERR_HIP;
+    }
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming) != hipSuccess) {
+        fbsmi_lg_sweep_destroy(s);
+        return fail(FBSMI_ERR_HIP, "lg_sweep_create: stream/event creation failed");
+    }
+    *out = s;
+    return FBSMI_OK;
+}
+
+void fbsmi_lg_sweep_destroy(fbsmi_lg_sweep* s) {
+    if (!s) return;
+    if (s->stream) hipStreamSynchronize(s->stream);
+    if (s->graph_single) hipGraphExecDestroy(s->graph_single);
+    if (s->graph_chain) hipGraphExecDestroy(s->graph_chain);
+    for (int w = 0; w < kNumProfKernels; ++w)
+        for (auto e : s->prof_ev[w]) hipEventDestroy(e);
+    if (s->ev_in) hipEventDestroy(s->ev_in);
+    if (s->ev_out) hipEventDestroy(s->ev_out);
+    if (s->stream) hipStreamDestroy(s->stream);
+    for (void* p : s->allocs) hipFree(p);
+    delete s;
+}
+
+int fbsmi_lg_gibbs_sweep(fbsmi_lg_sweep* s, const uint32_t* key, const float* x0, const float* y0,
+                         const int32_t* bs_star, float* x0_next, float* us_star_next, int32_t* bs_next,
+                         uint8_t* acc, int use_graph, void* stream) {
+    if (!s || !key || !x0 || !y0 || !bs_star) return fail(FBSMI_ERR_ARG, "lg_gibbs_sweep: null input");
+    hipStream_t ust = (hipStream_t)stream;
+    const LgDev& d = s->d;
+    FBSMI_HIP_TRY(hipEventRecord(s->ev_in, ust));
+    FBSMI_HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_in, 0));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.key, key, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.x0, x0, d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.y0, y0, d.dv * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.bs, bs_star, (d.T + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+    int rc = run_sweep(s, 0, use_graph);
+    if (rc) return rc;
+    if (x0_next) FBSMI_HIP_TRY(hipMemcpyAsync(x0_next, d.x0n, d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    if (us_star_next)
+        FBSMI_HIP_TRY(hipMemcpyAsync(us_star_next, d.usn, (size_t)(d.T + 1) * d.du * sizeof(float),
+                                     hipMemcpyDeviceToDevice, s->stream));
+    if (bs_next) FBSMI_HIP_TRY(hipMemcpyAsync(bs_next, d.bsn, (d.T + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+    if (acc) FBSMI_HIP_TRY(hipMemcpyAsync(acc, d.acc, (d.T + 1), hipMemcpyDeviceToDevice, s->stream));
+    rc = collect_profile(s);
+    if (rc) return rc;
+    FBSMI_HIP_TRY(hipEventRecord(s->ev_out, s->stream));
+    FBSMI_HIP_TRY(hipStreamWaitEvent(ust, s->ev_out, 0));
+    return FBSMI_OK;
+}
+
+int fbsmi_lg_gibbs_chain(fbsmi_lg_sweep* s, uint32_t* key, float* x0, const float* y0, int32_t* bs_star,
+                         int32_t nsweeps, float* x0s, int use_graph, void* stream) {
+    if (!s || !key || !x0 || !y0 || !bs_star || nsweeps < 0) return fail(FBSMI_ERR_ARG, "lg_gibbs_chain: bad arguments");
+    hipStream_t ust = (hipStream_t)stream;
+    const LgDev& d = s->d;
+    FBSMI_HIP_TRY(hipEventRecord(s->ev_in, ust));
+    FBSMI_HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_in, 0));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.key, key, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.x0, x0, d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.y0, y0, d.dv * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.bs, bs_star, (d.T + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemsetAsync(d.counter, 0, sizeof(int32_t), s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.x0s_slot, &x0s, sizeof(float*), hipMemcpyHostToDevice, s->stream));
+    // the slot copy reads a host stack variable: make sure it has landed before we return
+    FBSMI_HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < nsweeps; ++i) {
+        int rc = run_sweep(s, 1, use_graph);
+        if (rc) return rc;
+    }
+    FBSMI_HIP_TRY(hipMemcpyAsync(key, d.key, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(x0, d.x0, d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(bs_star, d.bs, (d.T + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+    int rc = collect_profile(s);
+    if (rc) return rc;
+    FBSMI_HIP_TRY(hipEventRecord(s->ev_out, s->stream));
+    FBSMI_HIP_TRY(hipStreamWaitEvent(ust, s->ev_out, 0));
+    return FBSMI_OK;
+}
+
+int fbsmi_lg_sweep_view(fbsmi_lg_sweep* s, int which, void* dst, int64_t* count, void* stream) {
+    if (!s) return fail(FBSMI_ERR_ARG, "lg_sweep_view: null handle");
+    const LgDev& d = s->d;
+    const void* src = nullptr;
+    int64_t n = 0;
+    size_t esz = 4;
+    switch (which) {
+        case 0: src = d.usT; n = (int64_t)d.N * d.du; break;
+        case 1: src = d.lwn; n = d.N; break;
+        case 2: src = d.As; n = (int64_t)d.T * d.N; break;
+        case 3: src = d.uss; n = (int64_t)(d.T + 1) * d.N * d.du; break;
+        case 4: src = d.lwss; n = (int64_t)(d.T + 1) * d.N; break;
+        case 5: src = d.us_star; n = (int64_t)(d.T + 1) * d.du; break;
+        case 6: src = d.vs; n = (int64_t)(d.T + 1) * d.dv; break;
+        default: return fail(FBSMI_ERR_ARG, "lg_sweep_view: unknown view");
+    }
+    if (!src) n = 0;
+    if (count) *count = n;
+    if (dst && n > 0) {
+        hipStream_t ust = (hipStream_t)stream;
+        FBSMI_HIP_TRY(hipStreamSynchronize(s->stream));
+        FBSMI_HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * esz, hipMemcpyDeviceToDevice, ust));
+    }
+    return FBSMI_OK;
+}
+
+int fbsmi_lg_sweep_profile(fbsmi_lg_sweep* s, int enable) {
+    if (!s) return fail(FBSMI_ERR_ARG, "lg_sweep_profile: null handle");
+    s->profile = enable != 0;
+    for (int w = 0; w < kNumProfKernels; ++w) {
+        s->prof_us[w] = 0;
+        s->prof_n[w] = 0;
+    }
+    return FBSMI_OK;
+}
+
+int fbsmi_lg_sweep_kernel_us(fbsmi_lg_sweep* s, int which, double* avg_us, int64_t* launches) {
+    if (!s || which < 0 || which >= kNumProfKernels) return fail(FBSMI_ERR_ARG, "lg_sweep_kernel_us: bad arguments");
+    if (avg_us) *avg_us = s->prof_n[which] ? s->prof_us[which] / (double)s->prof_n[which] : 0.0;
+    if (launches) *launches = s->prof_n[which];
+    return FBSMI_OK;
+}
+
+}  // extern "C"

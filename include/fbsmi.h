@@ -1,0 +1,168 @@
+/*
+ * fbsmi.h -- C ABI of libfbsmi, the MI355X (gfx950) engine for the particle-Gibbs / CSMC / pMCMC
+ * hot path of zgbkdlm/fbs.
+ *
+ * The reference has no FFI: its boundary is the Python API of fbs.samplers / fbs.sdes on JAX
+ * arrays.  Each entry point below names the reference function(s) whose
+ * device work it performs; fbs_amd/ (Python, ctypes) keeps the reference's names and argument
+ * orders on top of it, and INTEGRATION.md shows the binding a maintainer of the reference would
+ * add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr()) unless
+ *     the parameter is documented "host";
+ *   - `stream` is a hipStream_t (NULL = default stream); all work is stream-ordered, nothing
+ *     synchronises, nothing allocates: scratch comes from the caller's workspace `ws`
+ *     (fbsmi_workspace_bytes);
+ *   - PRNG keys are JAX threefry keys, two uint32 passed by value as (k0, k1);
+ *   - return value 0 = OK, negative = error (fbsmi_last_error() gives the text); no exceptions
+ *     cross the ABI; calls are re-entrant across streams as long as workspaces differ;
+ *   - float data is float32, indices int32, row-major.
+ */
+#ifndef FBSMI_H
+#define FBSMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FBSMI_ABI_VERSION 1
+
+#define FBSMI_OK 0
+#define FBSMI_ERR_ARG (-1)
+#define FBSMI_ERR_HIP (-2)
+#define FBSMI_ERR_UNSUPPORTED (-3)
+
+int fbsmi_abi_version(void);
+const char* fbsmi_last_error(void);
+
+/* ---- PRNG (jax.random.*; call sites listed in SURVEY.md Appendix A) ------------------------- */
+/* jax.random.split(key, num) on the HOST (pure integer work; out is a host array of num*2). */
+void fbsmi_key_split(uint32_t k0, uint32_t k1, int num, uint32_t* out_host);
+int fbsmi_random_bits(uint32_t k0, uint32_t k1, int64_t n, uint32_t* out, void* stream);
+int fbsmi_uniform(uint32_t k0, uint32_t k1, int64_t n, float* out, void* stream);
+int fbsmi_normal(uint32_t k0, uint32_t k1, int64_t n, float* out, void* stream);
+int fbsmi_randint(uint32_t k0, uint32_t k1, int64_t n, int32_t lo, int32_t hi, int32_t* out, void* stream);
+
+/* ---- numeric specification probes (include/fbsmi_math.h evaluated on the device) ------------
+ * op: 0 exp, 1 log, 2 log1p, 3 erfinv, 4 sqrt, 5 x/y, 6 bits->normal (x reinterpreted as uint32). */
+int fbsmi_math_map(int op, const float* x, const float* y, int64_t n, float* out, void* stream);
+
+/* ---- tree reductions / scans -------------------------------------------------------------- */
+size_t fbsmi_workspace_bytes(int64_t n);
+/* jnp.cumsum (associative_scan order); out may alias x */
+int fbsmi_cumsum(const float* x, int64_t n, float* out, void* ws, void* stream);
+/* root of the pairwise tree over x (zero padded) -> out[0] */
+int fbsmi_sum(const float* x, int64_t n, float* out, void* ws, void* stream);
+/* jax.scipy.special.logsumexp -> out[0] */
+int fbsmi_logsumexp(const float* x, int64_t n, float* out, void* ws, void* stream);
+/* fbs/samplers/csmc/csmc.py:273-292 normalise: out = lw - logsumexp(lw) (exp'd unless log_space);
+ * out may alias lw; out_lse (nullable) receives the logsumexp. */
+int fbsmi_normalise(const float* lw, int64_t n, int log_space, float* out, float* out_lse, void* ws, void* stream);
+/* jnp.searchsorted(a, q, side='left') for m queries */
+int fbsmi_searchsorted(const float* a, int32_t n, const float* q, int64_t m, int32_t* out, void* stream);
+
+/* ---- resamplers ---------------------------------------------------------------------------- */
+/* fbs/samplers/resampling.py: kind 0 stratified :58, 1 systematic :54, 2 multinomial :62,
+ * 3 killing :71.  Reference signature f(weights, key). */
+int fbsmi_resample(int kind, const float* w, uint32_t k0, uint32_t k1, int32_t n, int32_t* idx, void* ws,
+                   void* stream);
+/* fbs/samplers/csmc/resamplings.py: kind 0 multinomial :10, 1 killing :40, 2 systematic :91
+ * (conditional systematic is NotImplementedError in the reference -> FBSMI_ERR_UNSUPPORTED).
+ * Reference signature f(key, weights, i, j, conditional). */
+int fbsmi_cond_resample(int kind, uint32_t k0, uint32_t k1, const float* w, int32_t i, int32_t j, int conditional,
+                        int32_t n, int32_t* idx, void* ws, void* stream);
+/* jax.random.choice(key, n, (), p=w): csmc.py:295-297 barker_move, smc.py:104 -> out[0] */
+int fbsmi_categorical(uint32_t k0, uint32_t k1, const float* w, int32_t n, int32_t* out, void* ws, void* stream);
+/* fbs/samplers/gibbs.py:171-214 force_move -> out_i[0], out_alpha[0] (out_alpha nullable) */
+int fbsmi_force_move(uint32_t k0, uint32_t k1, const float* w, int32_t k, int32_t n, int32_t* out_i,
+                     float* out_alpha, void* ws, void* stream);
+
+/* ---- data movement ------------------------------------------------------------------------- */
+/* jnp.take(src, idx, axis=0): dst[r, :] = src[idx[r], :], rows of d floats (csmc.py:140) */
+int fbsmi_gather_rows(const float* src, const int32_t* idx, int64_t n, int64_t d, float* dst, void* stream);
+/* x.at[row].set(v): dst[row, :] = src[:]  (csmc.py:143,152) */
+int fbsmi_set_row(float* dst, int64_t row, const float* src, int64_t d, void* stream);
+/* csmc.py:262-267 ancestor back-trace: Bs[T] = B_T[0]; Bs[k-1] = As[k-1, Bs[k]]; As is (T, n) */
+int fbsmi_backtrace(const int32_t* As, int32_t T, int32_t n, const int32_t* B_T, int32_t* Bs, void* stream);
+
+/* ---- single-trajectory SDE paths ------------------------------------------------------------
+ * out (T+1, D): out[0] = x0, out[k+1] = F[k]*out[k] + S[k]*xi[k]  -- the exact forward noising
+ * transition of simulate_cond_forward(keep_path=True), fbs/sdes/linear.py:190-221; xi (T, D). */
+int fbsmi_linear_path(const float* F, const float* S, const float* x0, const float* xi, int32_t T, int64_t D,
+                      float* out, void* stream);
+/* Euler-Maruyama with nsub sub-steps per interval for a drift affine in x:
+ *   x += (A[r] x + B[r] target) ddt[k] + S[r] sqrt(ddt[k]) xi,  r = k*nsub + j,
+ * xi = normal(keys[k], (nsub, D)) (fbs/sdes/simulators.py:53-106).  With the Doob bridge drift of a
+ * scalar linear SDE this is doob_bridge_simulator (simulators.py:126-160), the bridge_sampler of
+ * fbs/samplers/gibbs.py:17-20.  keys (T,2) uint32 device; out (T+1, D). */
+int fbsmi_affine_em_path(const uint32_t* keys, const float* A, const float* B, const float* S, const float* ddt,
+                         const float* target, const float* x0, int32_t T, int32_t nsub, int64_t D, int replace_last,
+                         float* out, void* stream);
+
+/* ---- fused linear-Gaussian sampler ------------------------------------
+ * The reverse drift of a scalar-coefficient linear SDE under a Gaussian prior is affine,
+ * f(z, t_k) = G_k z + g_k; the three closures of experiments/toy/gp_gibbs.py:120-135 then need no
+ * Python in the loop.  Tables (device, float32), T = number of steps, D = du + dv:
+ *   G [T][D][D], g [T][D], sd [T] = sqrt(dt)*dispersion, lognorm [T] = log(2 pi sd^2),
+ *   F [T], sqQ [T] forward transition ts[k] -> ts[k+1].                                        */
+typedef struct fbsmi_lg_model {
+    int32_t du, dv, T;
+    float dt;
+    const float* G;
+    const float* g;
+    const float* sd;
+    const float* lognorm;
+    const float* F;
+    const float* sqQ;
+} fbsmi_lg_model;
+
+/* The three model closures on (n, du) ROW-MAJOR particles for step k (t_prev = ts[k]); sd_k and
+ * lognorm_k are the host copies of sd[k], lognorm[k] (the tables themselves live on the device).
+ * transition_sampler / likelihood_logpdf / transition_logpdf of experiments/toy/gp_gibbs.py:120-135. */
+int fbsmi_lg_transition_sampler(const fbsmi_lg_model* m, int32_t k, float sd_k, float lognorm_k, const float* us_prev,
+                                const float* v_prev, uint32_t k0, uint32_t k1, int64_t n, float* us, void* stream);
+int fbsmi_lg_likelihood_logpdf(const fbsmi_lg_model* m, int32_t k, float sd_k, float lognorm_k, const float* v,
+                               const float* us_prev, const float* v_prev, int64_t n, float* lw, void* stream);
+int fbsmi_lg_transition_logpdf(const fbsmi_lg_model* m, int32_t k, float sd_k, float lognorm_k, const float* u,
+                               const float* us_prev, const float* v_prev, int64_t n, float* lw, void* stream);
+
+typedef struct fbsmi_lg_sweep fbsmi_lg_sweep; /* opaque: device buffers + captured hipGraph */
+
+/* Create the state for gibbs_kernel sweeps (fbs/samplers/gibbs.py:68-168, marg_y=False) with
+ * `nparticles` particles.  store_path != 0 keeps As / uss / log_wss (needed when
+ * explicit_backward == 0).  Allocates device memory (not stream-ordered; call once). */
+int fbsmi_lg_sweep_create(const fbsmi_lg_model* model, int32_t nparticles, int explicit_backward,
+                          int explicit_final, int store_path, fbsmi_lg_sweep** out);
+void fbsmi_lg_sweep_destroy(fbsmi_lg_sweep* s);
+/* One Gibbs sweep, everything on the device.  key (2 x uint32), x0 (du), y0 (dv), bs_star (T+1)
+ * are device inputs; x0_next (du), us_star_next (T+1,du), bs_next (T+1), acc (T+1 bytes) device
+ * outputs (may alias the inputs of the next call).  use_graph != 0 replays a hipGraph captured on
+ * the first call.  */
+int fbsmi_lg_gibbs_sweep(fbsmi_lg_sweep* s, const uint32_t* key, const float* x0, const float* y0,
+                         const int32_t* bs_star, float* x0_next, float* us_star_next, int32_t* bs_next,
+                         uint8_t* acc, int use_graph, void* stream);
+/* Chain `nsweeps` sweeps with the key schedule of the reference's drivers
+ * (key, subkey = split(key); sweep(subkey): tests/test_gibbs.py:115-118).  key / x0 / bs_star are
+ * updated in place; x0s (nullable) receives (nsweeps, du). */
+int fbsmi_lg_gibbs_chain(fbsmi_lg_sweep* s, uint32_t* key, float* x0, const float* y0, int32_t* bs_star,
+                         int32_t nsweeps, float* x0s, int use_graph, void* stream);
+/* Parity views of the last sweep: copies view `which` into dst (device, nullable) and reports its
+ * element count.  which: 0 final particles (n,du) row-major, 1 final normalised log-weights (n),
+ * 2 As (T,n) int32, 3 uss (T+1,n,du), 4 log_wss (T+1,n) [2-4 only with store_path],
+ * 5 us_star (T+1,du) and 6 vs (T+1,dv) of the sweep.  n = nparticles (+1 if explicit_final). */
+int fbsmi_lg_sweep_view(fbsmi_lg_sweep* s, int which, void* dst, int64_t* count, void* stream);
+/* HIP-event timing hooks: average duration in microseconds of the propagate ("Euler") kernel
+ * over the launches since the last reset; 0 launches -> returns 0. Only measured when
+ * fbsmi_lg_sweep_profile(s, 1) was set (events force non-graph launches). */
+int fbsmi_lg_sweep_profile(fbsmi_lg_sweep* s, int enable);
+int fbsmi_lg_sweep_kernel_us(fbsmi_lg_sweep* s, int which, double* avg_us, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FBSMI_H */

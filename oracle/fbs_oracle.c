@@ -515,7 +515,8 @@ ORC_API void orc_lg_fwd_sampler(const orc_lg* m, const uint32_t key[2], const fl
 /* ------------------------------------------------------------------------------------------ */
 /* csmc.forward_pass, fbs/samplers/csmc/csmc.py:80-164, with the LG closures and a selectable   */
 /* conditional resampler (0 = killing, 1 = multinomial).                                       */
-/* us0 (n,du) and lw0 (n) are what init_sampler / init_likelihood_logpdf returned (csmc.py:151,154)*/
+/* us0 (n,du) is what init_sampler returned (csmc.py:151); lw0 (n) what init_likelihood_logpdf      */
+/* returns, or NULL for the explicit_final rule of gibbs.py:136-137 (evaluated after the pin).   */
 /* Outputs As (T,n), log_wss (T+1,n), uss (T+1,n,du) may each be NULL (not stored).            */
 /* us_last (n,du) and lw_last (n) always receive the final particles / log-weights.           */
 /* ------------------------------------------------------------------------------------------ */
@@ -535,7 +536,10 @@ ORC_API void orc_csmc_forward_pass_lg(const orc_lg* m, const uint32_t key[2], co
 
     memcpy(us, us0, sizeof(float) * (size_t)n * du);
     memcpy(us + (size_t)bs_star[0] * du, us_star, sizeof(float) * (size_t)du); /* csmc.py:152 */
-    memcpy(lw, lw0, sizeof(float) * (size_t)n);
+    /* csmc.py:154 init_likelihood_logpdf(vs[0], us0, vs[1]) is evaluated on the PINNED us0.
+     * lw0 == NULL selects gibbs.py:136-137: likelihood_logpdf(vs[0], u0s, vs[1], ts[0]). */
+    if (lw0) memcpy(lw, lw0, sizeof(float) * (size_t)n);
+    else orc_lg_likelihood_logpdf(m, 0, vs, us, vs + dv, n, lw);
     orc_normalise(lw, n, 1);                                                   /* csmc.py:155 */
     if (log_wss) memcpy(log_wss, lw, sizeof(float) * (size_t)n);
     if (uss) memcpy(uss, us, sizeof(float) * (size_t)n * du);
@@ -663,7 +667,8 @@ ORC_API void orc_gibbs_kernel_lg(const orc_lg* m, const uint32_t key[2], const f
         uint32_t kis[4];
         orc_split(key_csmc_fwd, 2, kis);
         orc_normal(kis, (int64_t)n * du, us0);
-        orc_lg_likelihood_logpdf(m, 0, vs, us0, vs + dv, n, lw0); /* likelihood_logpdf(vs[0], u0s, vs[1], ts[0]) */
+        free(lw0);
+        lw0 = NULL; /* computed inside forward_pass, after the pin */
     } else {
         for (int32_t p = 0; p < n; ++p) memcpy(us0 + (size_t)p * du, us, sizeof(float) * (size_t)du);
         const float c = (float)(-log((double)nparticles));
