@@ -115,6 +115,46 @@ __device__ __forceinline__ int searchsorted_left(const float* __restrict__ a, in
 }
 
 // ------------------------------------------------------------------------------------------
+// cross-lane partners for butterfly trees.  At level m every lane of an aligned 2^m-lane block
+// holds the same value, so "the value held by the sibling block" can be fetched from ANY lane of
+// that block: DPP quad permutes / row mirrors and the gfx950 row swaps (v_permlane16_swap,
+// v_permlane32_swap) do it in a few cycles, where __shfl_xor costs an LDS-crossbar round trip.
+// All 64 lanes must be active.
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+template <int M>
+__device__ __forceinline__ float tree_partner(float v) {
+    if constexpr (M == 1) return dpp_mov<0xB1>(v);         // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) return dpp_mov<0x141>(v);   // row_half_mirror: lane i <-> 7-i
+    else if constexpr (M == 8) return dpp_mov<0x140>(v);   // row_mirror: lane i <-> 15-i
+    else if constexpr (M == 16) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        return __builtin_bit_cast(float, ((threadIdx.x >> 4) & 1) ? r[0] : r[1]);
+    } else {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return __builtin_bit_cast(float, ((threadIdx.x >> 5) & 1) ? r[0] : r[1]);
+    }
+}
+
+// max over the 64 lanes (every lane receives it)
+__device__ __forceinline__ float wave_max(float m) {
+    m = fmaxf(m, tree_partner<1>(m));
+    m = fmaxf(m, tree_partner<2>(m));
+    m = fmaxf(m, tree_partner<4>(m));
+    m = fmaxf(m, tree_partner<8>(m));
+    m = fmaxf(m, tree_partner<16>(m));
+    m = fmaxf(m, tree_partner<32>(m));
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------
 // canonical tree inside one workgroup of kBlock threads
 //
 // Inclusive scan in lax.associative_scan order = a two-value descent of the index-bit tree.
@@ -127,28 +167,66 @@ __device__ __forceinline__ int searchsorted_left(const float* __restrict__ a, in
 struct TreePath {
     float ls[8];   // sibling sums: [0..5] lane levels (partner's block), [6] other wave of the pair, [7] waves 0+1
     float own[7];  // own block sums before combining: [0..5] lane levels, [6] own wave total
+    float hi;      // waves 2+3
 };
+
+#define FBSMI_TREE_LEVEL(m, M)                          \
+    {                                                   \
+        const float o_ = tree_partner<M>(s);            \
+        path.ls[m] = o_;                                \
+        path.own[m] = s;                                \
+        s = ((lane >> m) & 1) ? o_ + s : s + o_;        \
+    }
+
+// lane levels of the up-sweep: returns the wave total (every lane)
+__device__ __forceinline__ float wave_upsweep(float s, TreePath& path) {
+    const int lane = threadIdx.x & 63;
+    FBSMI_TREE_LEVEL(0, 1)
+    FBSMI_TREE_LEVEL(1, 2)
+    FBSMI_TREE_LEVEL(2, 4)
+    FBSMI_TREE_LEVEL(3, 8)
+    FBSMI_TREE_LEVEL(4, 16)
+    FBSMI_TREE_LEVEL(5, 32)
+    return s;
+}
+
+// wave levels, from the four wave totals
+__device__ __forceinline__ float waves_combine(float w0, float w1, float w2, float w3, float mine, TreePath& path) {
+    const int wave = threadIdx.x >> 6;
+    const float s01 = w0 + w1, s23 = w2 + w3;
+    path.own[6] = mine;
+    path.ls[6] = (wave & 2) ? ((wave & 1) ? w2 : w3) : ((wave & 1) ? w0 : w1);
+    path.ls[7] = s01;
+    path.hi = s23;
+    return s01 + s23;
+}
 
 // Up-sweep. `s` is the tree sum of this thread's own chunk.  Returns the tile total to every
 // thread.  `lds4` is 4 floats of LDS scratch (reusable after the call returns).
 __device__ __forceinline__ float block_upsweep(float s, TreePath& path, float* lds4) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int m = 0; m < 6; ++m) {
-        const float o = __shfl_xor(s, 1 << m);
-        path.ls[m] = o;
-        path.own[m] = s;
-        s = ((lane >> m) & 1) ? o + s : s + o;
-    }
+    s = wave_upsweep(s, path);
     __syncthreads();  // protect lds4 against a previous use
     if (lane == 0) lds4[wave] = s;
     __syncthreads();
-    const float w0 = lds4[0], w1 = lds4[1], w2 = lds4[2], w3 = lds4[3];
-    const float s01 = w0 + w1, s23 = w2 + w3;
-    path.own[6] = s;
-    path.ls[6] = (wave & 2) ? ((wave & 1) ? w2 : w3) : ((wave & 1) ? w0 : w1);
-    path.ls[7] = s01;
-    return s01 + s23;
+    return waves_combine(lds4[0], lds4[1], lds4[2], lds4[3], s, path);
+}
+
+// K independent up-sweeps sharing ONE LDS exchange (one barrier pair).  `lds` holds 4*K floats
+// that no thread reads or writes between the previous barrier and this call.
+template <int K>
+__device__ __forceinline__ void block_upsweep_n(float (&s)[K], TreePath (&path)[K], float* lds, float (&tot)[K]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = wave_upsweep(s[k], path[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) lds[4 * k + wave] = s[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        tot[k] = waves_combine(lds[4 * k], lds[4 * k + 1], lds[4 * k + 2], lds[4 * k + 3], s[k], path[k]);
 }
 
 // Descent from the tile node (P, E) to this thread's chunk node.
@@ -243,19 +321,13 @@ __device__ __forceinline__ void top_tree(const float* __restrict__ part, int nb,
         // one wave does it in registers; every wave repeats it, so no barrier is needed
         const int lane = threadIdx.x & 63;
         float s = lane < nb ? (lane == ov_idx ? ov_val : part[lane]) : 0.0f;
-        float ls[6], own[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            const float o = __shfl_xor(s, 1 << m);
-            ls[m] = o;
-            own[m] = s;
-            s = ((lane >> m) & 1) ? o + s : s + o;
-        }
+        TreePath path;
+        s = wave_upsweep(s, path);
         float p = 0.0f, e = s;
 #pragma unroll
         for (int m = 5; m >= 0; --m) {
             const bool right = (lane >> m) & 1;
-            const float t = p + (right ? ls[m] : own[m]);
+            const float t = p + (right ? path.ls[m] : path.own[m]);
             if (right) p = t; else e = t;
         }
         root = s;
@@ -294,8 +366,7 @@ __device__ __forceinline__ void top_tree(const float* __restrict__ part, int nb,
 __device__ __forceinline__ float top_max(const float* __restrict__ part, int nb, float* lds4) {
     float m = -__builtin_inff();
     for (int i = threadIdx.x; i < nb; i += kBlock) m = fmaxf(m, part[i]);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    m = wave_max(m);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -304,12 +375,116 @@ __device__ __forceinline__ float top_max(const float* __restrict__ part, int nb,
 }
 
 __device__ __forceinline__ float block_max(float m, float* lds4) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    m = wave_max(m);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = m;
     __syncthreads();
     return fmaxf(fmaxf(lds4[0], lds4[1]), fmaxf(lds4[2], lds4[3]));
+}
+
+// ------------------------------------------------------------------------------------------
+// Top-level tree for up to 1024 per-workgroup partials, shaped like a tile: every thread owns four
+// consecutive partials (zero beyond nb; a zero-padded tree has the same root and the same (P, E)).
+// Costs one LDS exchange for the up-sweep (shareable through the *_n form) and, when a leaf's
+// (P, E) is wanted, one more to broadcast it.
+// ------------------------------------------------------------------------------------------
+constexpr int kTopItems = 4;
+constexpr int kMaxTopBlock = kBlock * kTopItems;
+
+__device__ __forceinline__ void top_load(const float* __restrict__ part, int nb, float (&x)[kTopItems],
+                                         int ov_idx = -1, float ov_val = 0.0f) {
+#pragma unroll
+    for (int i = 0; i < kTopItems; ++i) {
+        const int e = threadIdx.x * kTopItems + i;
+        x[i] = e < nb ? (e == ov_idx ? ov_val : part[e]) : 0.0f;
+    }
+}
+
+__device__ __forceinline__ float top_load_max(const float* __restrict__ part, int nb) {
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < kTopItems; ++i) {
+        const int e = threadIdx.x * kTopItems + i;
+        if (e < nb) m = fmaxf(m, part[e]);
+    }
+    return m;
+}
+
+// (P, E) of leaf `b` from the up-swept top tile; `bc` = 2 floats of LDS; includes one barrier.
+__device__ __forceinline__ void top_leaf(const float (&x)[kTopItems], const TreePath& path, float root, int b,
+                                         float* bc, float& P, float& E) {
+    float p = 0.0f, e = root;
+    block_descend(p, e, path);
+    if ((int)threadIdx.x == (b >> 2)) {
+        // two in-chunk levels
+        const float s01 = x[0] + x[1];
+        float t = p + s01;
+        if (b & 2) p = t; else e = t;
+        t = p + ((b & 2) ? x[2] : x[0]);
+        if (b & 1) p = t; else e = t;
+        bc[0] = p;
+        bc[1] = e;
+    }
+    __syncthreads();
+    P = bc[0];
+    E = bc[1];
+}
+
+// ------------------------------------------------------------------------------------------
+// Fast exact bisection.  The first Lh <= 8 levels of the fixed bisection visit a fixed implicit
+// tree of at most 255 array positions: a workgroup gathers them into LDS once (one memory round
+// trip), and every search walks them there.  The remaining levels go three at a time: the 7
+// candidate positions of a 3-level subtree are loaded together, so a search costs
+// ceil(rem/3) dependent round trips instead of rem.  Running a few levels more than
+// ceil(log2(n+1)) is harmless: once the interval has collapsed every further level repeats a
+// comparison already made (same operands, same outcome).
+// ------------------------------------------------------------------------------------------
+constexpr int kHeapLevels = 8;
+constexpr int kHeapSize = 1 << kHeapLevels;
+
+__device__ __forceinline__ int heap_node_mid(int t, int n) {
+    int lo = 0, hi = n;
+    const int l = 31 - __builtin_clz(t);
+    for (int i = l - 1; i >= 0; --i) {
+        const int mid = (lo + hi) >> 1;
+        if ((t >> i) & 1) lo = mid; else hi = mid;
+    }
+    return (lo + hi) >> 1;
+}
+
+struct BisectState {
+    int lo, hi;
+};
+
+__device__ __forceinline__ int bisect_heap(const float* __restrict__ a, int n, int levels, const float* heap,
+                                           float q) {
+    int lo = 0, hi = n, t = 1;
+    const int Lh = levels < kHeapLevels ? levels : kHeapLevels;
+    for (int l = 0; l < Lh; ++l) {
+        const int mid = (lo + hi) >> 1;
+        const bool gl = q <= heap[t];
+        hi = gl ? mid : hi;
+        lo = gl ? lo : mid;
+        t = 2 * t + (gl ? 0 : 1);
+    }
+    for (int rem = levels - Lh; rem > 0; rem -= 3) {
+        const int m1 = (lo + hi) >> 1;
+        const int m2l = (lo + m1) >> 1, m2r = (m1 + hi) >> 1;
+        const int m3a = (lo + m2l) >> 1, m3b = (m2l + m1) >> 1, m3c = (m1 + m2r) >> 1, m3d = (m2r + hi) >> 1;
+        const float v1 = a[m1], v2l = a[m2l], v2r = a[m2r], v3a = a[m3a], v3b = a[m3b], v3c = a[m3c], v3d = a[m3d];
+        const bool g1 = q <= v1;
+        hi = g1 ? m1 : hi;
+        lo = g1 ? lo : m1;
+        const int m2 = g1 ? m2l : m2r;
+        const bool g2 = q <= (g1 ? v2l : v2r);
+        hi = g2 ? m2 : hi;
+        lo = g2 ? lo : m2;
+        const int m3 = g1 ? (g2 ? m3a : m3b) : (g2 ? m3c : m3d);
+        const bool g3 = q <= (g1 ? (g2 ? v3a : v3b) : (g2 ? v3c : v3d));
+        hi = g3 ? m3 : hi;
+        lo = g3 ? lo : m3;
+    }
+    return hi;
 }
 
 // logsumexp's "amax if finite else 0" (jax.scipy.special.logsumexp)

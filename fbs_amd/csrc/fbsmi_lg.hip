@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <vector>
@@ -144,20 +145,47 @@ __global__ void k_lg_noise(LgDev d) {
 // x_{k+1} = F_k x_k + sqrt(Q_k) xi_k (linear.py:211-221), one thread per coordinate; then the
 // time reversal and unpack of gibbs.py:128-130.  which = 0: from (x0, y0) -> us_star, vs;
 // which = 1: from (x0n, y0) -> usn (gibbs.py:155), bs_next, acc (gibbs.py:156,168).
+// The recurrence is sequential in k; its operands are not, so they are fetched kPathChunk steps
+// ahead (independent loads in flight) while the previous chunk is being folded in.
+constexpr int kPathChunk = 16;
+
 __global__ void k_lg_path(LgDev d, int which) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const float* xi = which ? d.xi2 : d.xi1;
     if (c < d.D) {
         float x = c < d.du ? (which ? d.x0n[c] : d.x0[c]) : d.y0[c - d.du];
-        for (int k = 0; k <= d.T; ++k) {
-            const int rk = d.T - k;  // reversed index
-            if (c < d.du) {
-                if (which) d.usn[(size_t)rk * d.du + c] = x;
-                else d.us_star[(size_t)rk * d.du + c] = x;
-            } else if (!which) {
-                d.vs[(size_t)rk * d.dv + (c - d.du)] = x;
+        float* dst = c < d.du ? (which ? d.usn : d.us_star) : (which ? nullptr : d.vs);
+        const int stride = c < d.du ? d.du : d.dv;
+        const int col = c < d.du ? c : c - d.du;
+        float F[kPathChunk], S[kPathChunk], Z[kPathChunk];
+        auto fetch = [&](int k0) {
+#pragma unroll
+            for (int j = 0; j < kPathChunk; ++j) {
+                const int k = k0 + j < d.T ? k0 + j : d.T - 1;
+                F[j] = d.F[k];
+                S[j] = d.sqQ[k];
+                Z[j] = xi[(size_t)k * d.D + c];
             }
-            if (k < d.T) x = d.F[k] * x + d.sqQ[k] * xi[(size_t)k * d.D + c];
+        };
+        if (dst) dst[(size_t)d.T * stride + col] = x;
+        fetch(0);
+        for (int k0 = 0; k0 < d.T; k0 += kPathChunk) {
+            float f[kPathChunk], sq[kPathChunk], z[kPathChunk];
+#pragma unroll
+            for (int j = 0; j < kPathChunk; ++j) {
+                f[j] = F[j];
+                sq[j] = S[j];
+                z[j] = Z[j];
+            }
+            if (k0 + kPathChunk < d.T) fetch(k0 + kPathChunk);
+#pragma unroll
+            for (int j = 0; j < kPathChunk; ++j) {
+                const int k = k0 + j;
+                if (k < d.T) {
+                    x = f[j] * x + sq[j] * z[j];
+                    if (dst) dst[(size_t)(d.T - 1 - k) * stride + col] = x;
+                }
+            }
         }
     }
     if (which) {
@@ -271,19 +299,35 @@ __global__ void __launch_bounds__(kBlock) k_lg_init(LgDev d) {
 }
 
 // ------------------------------------------------------------------------------------------
-// sumexp: per-workgroup tree sums of exp(lw - amax)
+// The four step kernels.  Each is latency-bound (a few hundred bytes per workgroup), so they are
+// written to keep the dependent chain short: every global load whose address is known is issued
+// at entry, reductions that are independent share one LDS exchange (block_upsweep_n), the
+// per-workgroup partials of the previous kernel are re-reduced through a tile-shaped top tree
+// (top_load / top_leaf) and searches use bisect_heap.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_max4(float m, float* lds4) {  // lds4 untouched since the last barrier
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(lds4[0], lds4[1]), fmaxf(lds4[2], lds4[3]));
+}
+
+// sumexp: per-workgroup tree sums of exp(lw - amax)   (logsumexp, csmc.py:289)
 template <int ITEMS>
 __global__ void __launch_bounds__(kBlock) k_lg_sumexp(LgDev d) {
-    __shared__ float s4[4];
-    const float M = finite_or_zero(top_max(d.bmax, d.nb, s4));
+    __shared__ float xch[2][4];
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    float l[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) l[i] = base + i < d.N ? d.lw[base + i] : 0.0f;
+    const float M = finite_or_zero(block_max4(top_load_max(d.bmax, d.nb), xch[0]));
     float x[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) x[i] = base + i < d.N ? fbsmi_expf(d.lw[base + i] - M) : 0.0f;
-    TreePath path;
-    const float tot = block_upsweep(chunk_total<ITEMS>(x), path, s4);
-    if (threadIdx.x == 0) d.bsumexp[blockIdx.x] = tot;
+    for (int i = 0; i < ITEMS; ++i) x[i] = base + i < d.N ? fbsmi_expf(l[i] - M) : 0.0f;
+    float sv[1] = {chunk_total<ITEMS>(x)}, tot[1];
+    TreePath path[1];
+    block_upsweep_n<1>(sv, path, xch[1], tot);
+    if (threadIdx.x == 0) d.bsumexp[blockIdx.x] = tot[0];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -300,17 +344,26 @@ __device__ __forceinline__ float fm_rest_at(float w, float w_k, bool is_k, int N
 
 template <int ITEMS, int MODE>
 __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev d, int s) {
-    __shared__ float s4[4];
-    __shared__ float s_top[kMaxNbSweep];
-    const float Mraw = top_max(d.bmax, d.nb, s4);
-    const float M = finite_or_zero(Mraw);
-    float S, dP, dE;
-    top_tree(d.bsumexp, d.nb, 0, s_top, S, dP, dE);
-    const float lse = fbsmi_logf(S) + M;
-    const float w_max = fbsmi_expf(Mraw - lse);
-    const int i_ref = d.bs[MODE == 0 ? s : d.T];
-    const float w_k = MODE == 1 ? fbsmi_expf(d.lw[i_ref] - lse) : 0.0f;
+    __shared__ float xch[4][4];
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    const int i_ref = d.bs[MODE == 0 ? s : d.T];
+    float l[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) l[i] = base + i < d.N ? d.lw[base + i] : 0.0f;
+    const float l_ref = MODE == 1 ? d.lw[i_ref] : 0.0f;
+    float bs4[kTopItems];
+    top_load(d.bsumexp, d.nb, bs4);
+    float mloc = top_load_max(d.bmax, d.nb);
+    // max of the maxima and root of the sumexp partials: one exchange
+    float sv[1] = {chunk_total<kTopItems>(bs4)}, tot[1];
+    TreePath tp[1];
+    mloc = wave_max(mloc);
+    if ((threadIdx.x & 63) == 0) xch[0][threadIdx.x >> 6] = mloc;
+    block_upsweep_n<1>(sv, tp, xch[1], tot);
+    const float Mraw = fmaxf(fmaxf(xch[0][0], xch[0][1]), fmaxf(xch[0][2], xch[0][3]));
+    const float lse = fbsmi_logf(tot[0]) + finite_or_zero(Mraw);
+    const float w_max = fbsmi_expf(Mraw - lse);  // == max_i w_i: fbsmi_expf is monotone
+    const float w_k = MODE == 1 ? fbsmi_expf(l_ref - lse) : 0.0f;
     float xw[ITEMS], xj[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -318,7 +371,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev d, int s) {
         xw[i] = 0.0f;
         xj[i] = 0.0f;
         if (e < d.N) {
-            const float ln = d.lw[e] - lse;
+            const float ln = l[i] - lse;
             const float w = fbsmi_expf(ln);
             d.w[e] = w;
             d.lwn[e] = ln;
@@ -328,19 +381,17 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev d, int s) {
             if (MODE == 1) xj[i] = fm_rest_at(w, w_k, e == i_ref, d.N);
         }
     }
-    TreePath path;
-    if (MODE != 1) {
-        const float tw = block_upsweep(chunk_total<ITEMS>(xw), path, s4);
-        if (threadIdx.x == 0) d.bsumw[blockIdx.x] = tw;
-    }
-    if (MODE != 2) {
-        const float tj = block_upsweep(chunk_total<ITEMS>(xj), path, s4);
-        if (threadIdx.x == 0) d.bsumJ[blockIdx.x] = tj;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        d.scal[0] = lse;
-        d.scal[1] = w_max;
-        d.scal[2] = w_k;
+    float s2[2] = {chunk_total<ITEMS>(xw), chunk_total<ITEMS>(xj)}, t2[2];
+    TreePath p2[2];
+    block_upsweep_n<2>(s2, p2, xch[2], t2);
+    if (threadIdx.x == 0) {
+        if (MODE != 1) d.bsumw[blockIdx.x] = t2[0];
+        if (MODE != 2) d.bsumJ[blockIdx.x] = t2[1];
+        if (blockIdx.x == 0) {
+            d.scal[0] = lse;
+            d.scal[1] = w_max;
+            d.scal[2] = w_k;
+        }
     }
 }
 
@@ -350,70 +401,119 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev d, int s) {
 // ------------------------------------------------------------------------------------------
 template <int ITEMS, int MODE>
 __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev d, int s) {
-    __shared__ float s4[4];
-    __shared__ float s_top[kMaxNbSweep];
+    __shared__ float xch[8][4];
+    __shared__ float bc[4][2];
     constexpr int TILE = kBlock * ITEMS;
+    const int b = blockIdx.x;
+    const int i_ref = d.bs[MODE == 0 ? s : d.T];
+    const int base = (b * kBlock + threadIdx.x) * ITEMS;
+    // ---- everything addressable now is loaded now
     const float w_max = d.scal[1];
     const float w_k = d.scal[2];
-    const int i_ref = d.bs[MODE == 0 ? s : d.T];
-    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
-    TreePath path;
-    float root, P, E;
-    if (MODE == 0 || MODE == 2) {
-        top_tree(d.bsumw, d.nb, blockIdx.x, s_top, root, P, E);
-        float x[ITEMS], c[ITEMS];
+    float wv[ITEMS];
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) x[i] = base + i < d.N ? d.w[base + i] : 0.0f;
-        block_upsweep(chunk_total<ITEMS>(x), path, s4);
-        block_descend(P, E, path);
-        chunk_scan<ITEMS>(x, P, E, c);
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i)
-            if (base + i < d.N) d.cdf[base + i] = c[i];
-    }
-    if (MODE == 0) {
-        // J_prob[i*] = max(1 - sum(J_prob with [i*] = 0), 0)   (resamplings.py:80-82)
-        float SJ, dP, dE;
-        top_tree(d.bsumJ, d.nb, 0, s_top, SJ, dP, dE);
-        const float Ji = fmaxf(1.0f - SJ, 0.0f);
-        // the tile that holds i* has a new tree sum: every workgroup rebuilds it
-        const int b_ref = i_ref / TILE;
-        const int rbase = b_ref * TILE + threadIdx.x * ITEMS;
-        float x[ITEMS], c[ITEMS];
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int e = rbase + i;
-            x[i] = e < d.N ? (e == i_ref ? Ji : jprob_at(d.w[e], w_max, d.N)) : 0.0f;
-        }
-        const float newsum = block_upsweep(chunk_total<ITEMS>(x), path, s4);
-        top_tree(d.bsumJ, d.nb, blockIdx.x, s_top, root, P, E, b_ref, newsum);
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int e = base + i;
-            x[i] = e < d.N ? (e == i_ref ? Ji : jprob_at(d.w[e], w_max, d.N)) : 0.0f;
-        }
-        block_upsweep(chunk_total<ITEMS>(x), path, s4);
-        block_descend(P, E, path);
-        chunk_scan<ITEMS>(x, P, E, c);
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i)
-            if (base + i < d.N) d.cdfJ[base + i] = c[i];
-    }
+    for (int i = 0; i < ITEMS; ++i) wv[i] = base + i < d.N ? d.w[base + i] : 0.0f;
     if (MODE == 1) {
-        top_tree(d.bsumJ, d.nb, blockIdx.x, s_top, root, P, E);
+        float pj[kTopItems];
+        top_load(d.bsumJ, d.nb, pj);
         float x[ITEMS], c[ITEMS];
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int e = base + i;
-            x[i] = e < d.N ? fm_rest_at(d.w[e], w_k, e == i_ref, d.N) : 0.0f;
-        }
-        block_upsweep(chunk_total<ITEMS>(x), path, s4);
-        block_descend(P, E, path);
+        for (int i = 0; i < ITEMS; ++i) x[i] = base + i < d.N ? fm_rest_at(wv[i], w_k, base + i == i_ref, d.N) : 0.0f;
+        float s2[2] = {chunk_total<kTopItems>(pj), chunk_total<ITEMS>(x)}, t2[2];
+        TreePath p2[2];
+        block_upsweep_n<2>(s2, p2, xch[0], t2);
+        float P, E;
+        top_leaf(pj, p2[0], t2[0], b, bc[0], P, E);
+        block_descend(P, E, p2[1]);
         chunk_scan<ITEMS>(x, P, E, c);
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i)
             if (base + i < d.N) d.cdf[base + i] = c[i];
+        return;
     }
+    float pw[kTopItems];
+    top_load(d.bsumw, d.nb, pw);
+    if (MODE == 2) {
+        float c[ITEMS];
+        float s2[2] = {chunk_total<kTopItems>(pw), chunk_total<ITEMS>(wv)}, t2[2];
+        TreePath p2[2];
+        block_upsweep_n<2>(s2, p2, xch[0], t2);
+        float P, E;
+        top_leaf(pw, p2[0], t2[0], b, bc[0], P, E);
+        block_descend(P, E, p2[1]);
+        chunk_scan<ITEMS>(wv, P, E, c);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (base + i < d.N) d.cdf[base + i] = c[i];
+        return;
+    }
+    // ---- MODE 0
+    const int b_ref = i_ref / TILE;
+    const int rbase = b_ref * TILE + threadIdx.x * ITEMS;
+    float wr[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) wr[i] = rbase + i < d.N ? d.w[rbase + i] : 0.0f;
+    float pj[kTopItems];
+    top_load(d.bsumJ, d.nb, pj);
+    // phase 1: top(bsumw), top(bsumJ) [for the total], own w tile -- one exchange
+    float s3[3] = {chunk_total<kTopItems>(pw), chunk_total<kTopItems>(pj), chunk_total<ITEMS>(wv)}, t3[3];
+    TreePath p3[3];
+    block_upsweep_n<3>(s3, p3, xch[0], t3);
+    // J_prob[i*] = max(1 - sum(J_prob with [i*] = 0), 0)   (resamplings.py:80-82)
+    const float Ji = fmaxf(1.0f - t3[1], 0.0f);
+    // phase 2: the tile that holds i* (its tree sum changes) and this workgroup's own J tile
+    float xr[ITEMS], xo[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int er = rbase + i, eo = base + i;
+        xr[i] = er < d.N ? (er == i_ref ? Ji : jprob_at(wr[i], w_max, d.N)) : 0.0f;
+        xo[i] = eo < d.N ? (eo == i_ref ? Ji : jprob_at(wv[i], w_max, d.N)) : 0.0f;
+    }
+    float s2[2] = {chunk_total<ITEMS>(xr), chunk_total<ITEMS>(xo)}, t2[2];
+    TreePath p2[2];
+    block_upsweep_n<2>(s2, p2, xch[3], t2);
+    // phase 3: top tree of the J partials with the rebuilt tile substituted
+    float pj2[kTopItems];
+#pragma unroll
+    for (int i = 0; i < kTopItems; ++i) pj2[i] = (int)threadIdx.x * kTopItems + i == b_ref ? t2[0] : pj[i];
+    float s1[1] = {chunk_total<kTopItems>(pj2)}, t1[1];
+    TreePath p1[1];
+    block_upsweep_n<1>(s1, p1, xch[5], t1);
+    // (P, E) of this workgroup's tile in both trees (one barrier for both broadcasts)
+    {
+        float pw_p = 0.0f, pw_e = t3[0], pj_p = 0.0f, pj_e = t1[0];
+        block_descend(pw_p, pw_e, p3[0]);
+        block_descend(pj_p, pj_e, p1[0]);
+        if ((int)threadIdx.x == (b >> 2)) {
+            float t = pw_p + (pw[0] + pw[1]);
+            if (b & 2) pw_p = t; else pw_e = t;
+            t = pw_p + ((b & 2) ? pw[2] : pw[0]);
+            if (b & 1) pw_p = t; else pw_e = t;
+            bc[0][0] = pw_p;
+            bc[0][1] = pw_e;
+            t = pj_p + (pj2[0] + pj2[1]);
+            if (b & 2) pj_p = t; else pj_e = t;
+            t = pj_p + ((b & 2) ? pj2[2] : pj2[0]);
+            if (b & 1) pj_p = t; else pj_e = t;
+            bc[1][0] = pj_p;
+            bc[1][1] = pj_e;
+        }
+        __syncthreads();
+    }
+    float P = bc[0][0], E = bc[0][1];
+    float c[ITEMS];
+    block_descend(P, E, p3[2]);
+    chunk_scan<ITEMS>(wv, P, E, c);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (base + i < d.N) d.cdf[base + i] = c[i];
+    P = bc[1][0];
+    E = bc[1][1];
+    block_descend(P, E, p2[1]);
+    chunk_scan<ITEMS>(xo, P, E, c);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (base + i < d.N) d.cdfJ[base + i] = c[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -421,30 +521,36 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev d, int s) {
 // ------------------------------------------------------------------------------------------
 template <int ITEMS, int DMAX>
 __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev d, int s) {
-    __shared__ float s4[4];
-    __shared__ int s_shift;
+    __shared__ float xch[4];
+    __shared__ float heapW[kHeapSize], heapJ[kHeapSize];
     const int N = d.N;
     const uint32_t* kt = d.keytab + 8 * s;
     const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5], t0 = kt[6], t1 = kt[7];
     const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
-    if (threadIdx.x == 0) {
-        // J = choice(key_3, N, (), p=J_prob)  (resamplings.py:84); roll by j - J (:85)
-        const float u3 = uniform_at(c0, c1, 1, 0);
-        const int J = searchsorted_left(d.cdfJ, N, d.levels, d.cdfJ[N - 1] * (1.0f - u3));
-        int sh = (j_ref - J) % N;
-        if (sh < 0) sh += N;
-        s_shift = sh;
-    }
-    __syncthreads();
-    const int shift = s_shift;
+    const float lastJ = d.cdfJ[N - 1];
     const float last = d.cdf[N - 1];
     const float w_max = d.scal[1];
+    if (threadIdx.x >= 1 && threadIdx.x < kHeapSize) {
+        const int mid = heap_node_mid(threadIdx.x, N);
+        heapW[threadIdx.x] = d.cdf[mid];
+        heapJ[threadIdx.x] = d.cdfJ[mid];
+    }
     const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
     float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
     const StepTables<DMAX> t = step_tables<DMAX>(d, s);
     const float* v_prev = d.vs + (size_t)s * d.dv;
     const float* v = d.vs + (size_t)(s + 1) * d.dv;
     const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
+    __syncthreads();
+    // J = choice(key_3, N, (), p=J_prob)  (resamplings.py:84); roll by j - J (:85).  Every thread
+    // repeats the (identical, broadcast-served) search: no further barrier is needed.
+    int shift;
+    {
+        const float u3 = uniform_at(c0, c1, 1, 0);
+        const int J = bisect_heap(d.cdfJ, N, d.levels, heapJ, lastJ * (1.0f - u3));
+        shift = (j_ref - J) % N;
+        if (shift < 0) shift += N;
+    }
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
     float mloc = -__builtin_inff();
 #pragma unroll
@@ -458,7 +564,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev d, int s) {
             int a = src;
             if (u1 * w_max >= ws) {  // killed (resamplings.py:71): redraw from Cat(w) (:73-74)
                 const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)src);
-                a = searchsorted_left(d.cdf, N, d.levels, last * (1.0f - u2));
+                a = bisect_heap(d.cdf, N, d.levels, heapW, last * (1.0f - u2));
             }
             if (m == j_ref) a = i_ref;  // :86
             if (d.As) d.As[(size_t)s * N + m] = a;
@@ -483,7 +589,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev d, int s) {
             mloc = fmaxf(mloc, l);
         }
     }
-    mloc = block_max(mloc, s4);
+    mloc = block_max4(mloc, xch);
     if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
 }
 
@@ -576,6 +682,7 @@ struct fbsmi_lg_sweep {
     hipGraphExec_t graph_single = nullptr;  // one sweep, no chain bookkeeping
     hipGraphExec_t graph_chain = nullptr;   // one sweep + key split + advance
     bool profile = false;
+    int debug_mask = 15;  // FBSMI_DEBUG_STEP_MASK: bit0 norm, bit1 cdf, bit2 prop, bit3 sumexp (timing experiments only)
     std::vector<hipEvent_t> prof_ev[kNumProfKernels];  // pairs (start, stop)
     double prof_us[kNumProfKernels] = {0, 0, 0, 0};
     int64_t prof_n[kNumProfKernels] = {0, 0, 0, 0};
@@ -650,19 +757,19 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     k_lg_path<<<gpath, 64, 0, st>>>(d, 0);
     LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<nb, kBlock, 0, st>>>(d)));
     for (int k = 0; k < d.T; ++k) {
-        {
+        if (s->debug_mask & 8) {
             ProfScope p(s, 3, st);
             LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<nb, kBlock, 0, st>>>(d)));
         }
-        {
+        if (s->debug_mask & 1) {
             ProfScope p(s, 0, st);
             LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 0><<<nb, kBlock, 0, st>>>(d, k)));
         }
-        {
+        if (s->debug_mask & 2) {
             ProfScope p(s, 1, st);
             LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 0><<<nb, kBlock, 0, st>>>(d, k)));
         }
-        {
+        if (s->debug_mask & 4) {
             ProfScope p(s, 2, st);
             LG_DISPATCH(s, (k_lg_prop<ITEMS, DMAX><<<nb, kBlock, 0, st>>>(d, k)));
         }
@@ -766,6 +873,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     d.lw_init = (float)(-log((double)nparticles));
     d.G = m->G; d.g = m->g; d.sd = m->sd; d.lognorm = m->lognorm; d.F = m->F; d.sqQ = m->sqQ;
     d.levels = bisect_levels(d.N);
+    if (const char* dm = getenv("FBSMI_DEBUG_STEP_MASK")) s->debug_mask = atoi(dm);
     s->items = d.N <= (1 << 17) ? 1 : (d.N <= (1 << 20) ? 4 : 16);
     const int maxd = m->du > m->dv ? m->du : m->dv;
     s->dmax = maxd <= 2 ? 2 : (maxd <= 4 ? 4 : 16);
