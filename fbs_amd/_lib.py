@@ -79,7 +79,7 @@ SIGNATURES = {
     "fbsmi_lg_transition_sampler": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _u32, _u32, _i64, _vp, _vp]),
     "fbsmi_lg_likelihood_logpdf": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _vp, _i64, _vp, _vp]),
     "fbsmi_lg_transition_logpdf": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "fbsmi_lg_sweep_create": (C.c_int, [C.POINTER(LGModelStruct), _i32, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "fbsmi_lg_sweep_create": (C.c_int, [C.POINTER(LGModelStruct), _i32, C.c_int, C.c_int, C.c_int, _i32, C.POINTER(_vp)]),
     "fbsmi_lg_sweep_destroy": (None, [_vp]),
     "fbsmi_lg_gibbs_sweep": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "fbsmi_lg_gibbs_chain": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_int, _vp]),

@@ -37,6 +37,7 @@ constexpr int kMaxNbSweep = 1024;  // workgroup partials one in-kernel top tree 
 constexpr int kNumProfKernels = 4; // norm, cdf, prop, sumexp
 
 struct LgDev {
+    int C;           // independent chains batched in every launch (blockIdx.y): jax.vmap over chains
     int N;           // rows of the particle system (nparticles, +1 when explicit_final)
     int nparticles;
     int du, dv, D, T;
@@ -47,10 +48,11 @@ struct LgDev {
     float lw_init;   // -log(nparticles)
     const float *G, *g, *sd, *lognorm, *F, *sqQ;
     // per-sweep inputs (internal copies)
-    uint32_t* key;   // [2]
-    float* x0;       // [du]
-    float* y0;       // [dv]
-    int32_t* bs;     // [T+1]
+    uint32_t* key;   // [2]     master key of the chain driver (shared)
+    uint32_t* keys;  // [C][2]  per-chain sweep keys
+    float* x0;       // [C][du]
+    float* y0;       // [dv]    shared by all chains (vmap in_axes=None, gp_gibbs.py:173)
+    int32_t* bs;     // [C][T+1]
     // derived per sweep
     uint32_t* keytab;  // [T][8]: key_1, key_2, key_3 of the killing resampler, key_transition
     uint32_t* misc;    // [16]: 0 key_fwd, 2 key_init, 4 key_x0(force_move), 6 key_us, 8 key_bs, 10 key_bwd
@@ -83,22 +85,59 @@ struct LgDev {
     int32_t* counter;  // device sweep counter
 };
 
+// The view of chain c: every per-chain array advanced to that chain's slice (all per-chain arrays
+// are laid out [C][...]).
+__device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
+    const size_t N = d.N, T = d.T, D = d.D, du = d.du, dv = d.dv, nb = d.nb;
+    d.keys += 2 * (size_t)c;
+    d.x0 += du * c;
+    d.bs += (T + 1) * c;
+    d.keytab += 8 * T * c;
+    d.misc += 16 * (size_t)c;
+    d.xi1 += T * D * c;
+    d.xi2 += T * D * c;
+    d.us_star += (T + 1) * du * c;
+    d.vs += (T + 1) * dv * c;
+    d.u0 += N * du * c;
+    d.u1 += N * du * c;
+    d.lw += N * c;
+    d.lwn += N * c;
+    d.w += N * c;
+    d.cdf += N * c;
+    d.cdfJ += N * c;
+    d.bmax += nb * c;
+    d.bsumexp += nb * c;
+    d.bsumw += nb * c;
+    d.bsumJ += nb * c;
+    d.scal += 16 * (size_t)c;
+    if (d.As) d.As += T * N * c;
+    if (d.uss) d.uss += (T + 1) * N * du * c;
+    if (d.lwss) d.lwss += (T + 1) * N * c;
+    d.usT += N * du * c;
+    d.x0n += du * c;
+    d.usn += (T + 1) * du * c;
+    d.bsn += (T + 1) * c;
+    d.acc += (T + 1) * c;
+    return d;
+}
+
 // ------------------------------------------------------------------------------------------
 // sweep prologue: key derivation, forward noising path
 // ------------------------------------------------------------------------------------------
 // gibbs.py:126,147 ; csmc.py:65,150,157,136 ; resamplings.py:66
-__global__ void __launch_bounds__(kBlock) k_lg_keys(LgDev d, int chain) {
+__global__ void __launch_bounds__(kBlock) k_lg_keys(LgDev dd, int chain) {
+    const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ uint32_t sk[4];
     if (threadIdx.x == 0) {
-        uint32_t k0 = d.key[0], k1 = d.key[1];
-        if (chain) {  // key, subkey = split(key)
-            uint32_t a0, a1, b0, b1;
-            split_at(k0, k1, 2, 0, a0, a1);
-            split_at(k0, k1, 2, 1, b0, b1);
-            d.key[0] = a0;
-            d.key[1] = a1;
-            k0 = b0;
-            k1 = b1;
+        uint32_t k0 = d.keys[0], k1 = d.keys[1];
+        if (chain) {
+            // chain driver: key, subkey = split(key) (the master key itself is advanced by
+            // k_lg_advance); one chain sweeps with subkey (tests/test_gibbs.py:116), a batch of C
+            // chains with split(subkey, C)[c] (experiments/toy/gp_gibbs.py:183-185)
+            uint32_t b0, b1;
+            split_at(d.key[0], d.key[1], 2, 1, b0, b1);
+            if (d.C > 1) split_at(b0, b1, d.C, blockIdx.y, k0, k1);
+            else { k0 = b0; k1 = b1; }
         }
         uint32_t f0, f1, c0, c1;
         split_at(k0, k1, 3, 0, f0, f1);  // key_fwd
@@ -134,7 +173,8 @@ __global__ void __launch_bounds__(kBlock) k_lg_keys(LgDev d, int chain) {
 }
 
 // normal(key, (T, D)) for both forward paths (linear.py:220)
-__global__ void k_lg_noise(LgDev d) {
+__global__ void k_lg_noise(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
     const uint64_t n = (uint64_t)d.T * d.D;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         d.xi1[i] = normal_at(d.misc[0], d.misc[1], n, i);
@@ -149,7 +189,8 @@ __global__ void k_lg_noise(LgDev d) {
 // ahead (independent loads in flight) while the previous chunk is being folded in.
 constexpr int kPathChunk = 16;
 
-__global__ void k_lg_path(LgDev d, int which) {
+__global__ void k_lg_path(LgDev dd, int which) {
+    const LgDev d = chain_view(dd, blockIdx.y);
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const float* xi = which ? d.xi2 : d.xi1;
     if (c < d.D) {
@@ -264,7 +305,8 @@ __device__ __forceinline__ float lg_loglik(const StepTables<DMAX>& t, const floa
 // init: csmc.py:150-155 with the init_sampler / init_likelihood_logpdf of gibbs.py:132-144
 // ------------------------------------------------------------------------------------------
 template <int ITEMS, int DMAX>
-__global__ void __launch_bounds__(kBlock) k_lg_init(LgDev d) {
+__global__ void __launch_bounds__(kBlock) k_lg_init(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float s4[4];
     const StepTables<DMAX> t = step_tables<DMAX>(d, 0);
     const int b0 = d.bs[0];
@@ -314,7 +356,8 @@ __device__ __forceinline__ float block_max4(float m, float* lds4) {  // lds4 unt
 
 // sumexp: per-workgroup tree sums of exp(lw - amax)   (logsumexp, csmc.py:289)
 template <int ITEMS>
-__global__ void __launch_bounds__(kBlock) k_lg_sumexp(LgDev d) {
+__global__ void __launch_bounds__(kBlock) k_lg_sumexp(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float xch[2][4];
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
     float l[ITEMS];
@@ -343,7 +386,8 @@ __device__ __forceinline__ float fm_rest_at(float w, float w_k, bool is_k, int N
 }
 
 template <int ITEMS, int MODE>
-__global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev d, int s) {
+__global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float xch[4][4];
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
     const int i_ref = d.bs[MODE == 0 ? s : d.T];
@@ -400,7 +444,8 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev d, int s) {
 //       MODE 2: cumsum(w) -> cdf.
 // ------------------------------------------------------------------------------------------
 template <int ITEMS, int MODE>
-__global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev d, int s) {
+__global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float xch[8][4];
     __shared__ float bc[4][2];
     constexpr int TILE = kBlock * ITEMS;
@@ -520,7 +565,8 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev d, int s) {
 // prop: resample (killing, conditional) + gather + Euler-Maruyama + pin + log-weight
 // ------------------------------------------------------------------------------------------
 template <int ITEMS, int DMAX>
-__global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev d, int s) {
+__global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float xch[4];
     __shared__ float heapW[kHeapSize], heapJ[kHeapSize];
     const int N = d.N;
@@ -530,10 +576,11 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev d, int s) {
     const float lastJ = d.cdfJ[N - 1];
     const float last = d.cdf[N - 1];
     const float w_max = d.scal[1];
+    float hw = 0.0f, hj = 0.0f;
     if (threadIdx.x >= 1 && threadIdx.x < kHeapSize) {
         const int mid = heap_node_mid(threadIdx.x, N);
-        heapW[threadIdx.x] = d.cdf[mid];
-        heapJ[threadIdx.x] = d.cdfJ[mid];
+        hw = d.cdf[mid];
+        hj = d.cdfJ[mid];
     }
     const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
     float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
@@ -541,17 +588,30 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev d, int s) {
     const float* v_prev = d.vs + (size_t)s * d.dv;
     const float* v = d.vs + (size_t)(s + 1) * d.dv;
     const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
+    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    // the slot's own noise depends on nothing that is still in flight: draw it while the heap
+    // gathers are outstanding
+    float xi[ITEMS][DMAX];
+    const float u3 = uniform_at(c0, c1, 1, 0);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r)
+            xi[i][r] = (r < d.du && base + i < N)
+                           ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)(base + i) * d.du + r) : 0.0f;
+    if (threadIdx.x < kHeapSize) {
+        heapW[threadIdx.x] = hw;
+        heapJ[threadIdx.x] = hj;
+    }
     __syncthreads();
     // J = choice(key_3, N, (), p=J_prob)  (resamplings.py:84); roll by j - J (:85).  Every thread
     // repeats the (identical, broadcast-served) search: no further barrier is needed.
     int shift;
     {
-        const float u3 = uniform_at(c0, c1, 1, 0);
         const int J = bisect_heap(d.cdfJ, N, d.levels, heapJ, lastJ * (1.0f - u3));
         shift = (j_ref - J) % N;
         if (shift < 0) shift += N;
     }
-    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
     float mloc = -__builtin_inff();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -576,8 +636,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev d, int s) {
             for (int r = 0; r < DMAX; ++r) {
                 if (r < d.du) {
                     const float dr = drift_row<DMAX>(t, r, u, v_prev);
-                    const float xi = normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r);
-                    float x = (u[r] + dr * t.dt) + t.sd * xi;
+                    float x = (u[r] + dr * t.dt) + t.sd * xi[i][r];
                     if (m == j_ref) x = ustar[r];
                     un[(size_t)r * N + m] = x;
                     if (d.uss) d.uss[((size_t)(s + 1) * N + m) * d.du + r] = x;
@@ -597,7 +656,8 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev d, int s) {
 // sweep epilogue
 // ------------------------------------------------------------------------------------------
 // explicit backward (gibbs.py:152-154): force_move tail, x0 = uss[-1, idx]
-__global__ void k_lg_force_move(LgDev d) {
+__global__ void k_lg_force_move(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
     const float* uT = (d.T & 1) ? d.u1 : d.u0;
     __shared__ int s_idx;
     if (threadIdx.x == 0) {
@@ -619,7 +679,8 @@ __global__ void k_lg_force_move(LgDev d) {
 }
 
 // backward scanning (csmc.py:230-270): B_T ~ Cat(w_T), B_{k-1} = A_k[B_k], x_k = uss[k, B_k]
-__global__ void k_lg_backscan(LgDev d) {
+__global__ void k_lg_backscan(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ int s_B[1];
     const int N = d.N;
     if (threadIdx.x == 0) {
@@ -643,7 +704,8 @@ __global__ void k_lg_backscan(LgDev d) {
 }
 
 // row-major copy of the final particles (parity view)
-__global__ void k_lg_export(LgDev d) {
+__global__ void k_lg_export(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
     const float* uT = (d.T & 1) ? d.u1 : d.u0;
     const size_t tot = (size_t)d.N * d.du;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
@@ -652,18 +714,29 @@ __global__ void k_lg_export(LgDev d) {
     }
 }
 
-// chain step: x0 <- x0_next, bs <- bs_next, x0s[counter++] = x0_next
-__global__ void k_lg_advance(LgDev d) {
-    const int c = *d.counter;
+// chain step, one workgroup per chain: x0 <- x0_next, bs <- bs_next, x0s[counter][c] = x0_next;
+// chain 0 also advances the master key (key = split(key)[0]) and the sweep counter.
+__global__ void k_lg_advance(LgDev dd) {
+    const int c = blockIdx.y;
+    const LgDev d = chain_view(dd, c);
+    const int cnt = *d.counter;
     float* x0s = d.x0s_slot ? *d.x0s_slot : nullptr;
     for (int r = threadIdx.x; r < d.du; r += blockDim.x) {
         const float x = d.x0n[r];
         d.x0[r] = x;
-        if (x0s) x0s[(size_t)c * d.du + r] = x;
+        if (x0s) x0s[((size_t)cnt * d.C + c) * d.du + r] = x;
     }
     for (int k = threadIdx.x; k <= d.T; k += blockDim.x) d.bs[k] = d.bsn[k];
-    __syncthreads();
-    if (threadIdx.x == 0) *d.counter = c + 1;
+}
+
+__global__ void k_lg_advance_key(LgDev d) {
+    if (threadIdx.x == 0) {
+        uint32_t a0, a1;
+        split_at(d.key[0], d.key[1], 2, 0, a0, a1);
+        d.key[0] = a0;
+        d.key[1] = a1;
+        *d.counter = *d.counter + 1;
+    }
 }
 
 }  // namespace fbsmi
@@ -746,52 +819,56 @@ struct ProfScope {
 int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     const LgDev& d = s->d;
     const int nb = d.nb;
-    k_lg_keys<<<1, kBlock, 0, st>>>(d, chain);
+    const dim3 gone(1, d.C), gtile(nb, d.C);
+    k_lg_keys<<<gone, kBlock, 0, st>>>(d, chain);
     {
         const int64_t n = (int64_t)d.T * d.D;
         int g = (int)((n + 255) / 256);
         g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-        k_lg_noise<<<g, 256, 0, st>>>(d);
+        k_lg_noise<<<dim3(g, d.C), 256, 0, st>>>(d);
     }
     const int gpath = (d.D + 63) / 64;
-    k_lg_path<<<gpath, 64, 0, st>>>(d, 0);
-    LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<nb, kBlock, 0, st>>>(d)));
+    k_lg_path<<<dim3(gpath, d.C), 64, 0, st>>>(d, 0);
+    LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d)));
     for (int k = 0; k < d.T; ++k) {
         if (s->debug_mask & 8) {
             ProfScope p(s, 3, st);
-            LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<nb, kBlock, 0, st>>>(d)));
+            LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<gtile, kBlock, 0, st>>>(d)));
         }
         if (s->debug_mask & 1) {
             ProfScope p(s, 0, st);
-            LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 0><<<nb, kBlock, 0, st>>>(d, k)));
+            LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 0><<<gtile, kBlock, 0, st>>>(d, k)));
         }
         if (s->debug_mask & 2) {
             ProfScope p(s, 1, st);
-            LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 0><<<nb, kBlock, 0, st>>>(d, k)));
+            LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 0><<<gtile, kBlock, 0, st>>>(d, k)));
         }
         if (s->debug_mask & 4) {
             ProfScope p(s, 2, st);
-            LG_DISPATCH(s, (k_lg_prop<ITEMS, DMAX><<<nb, kBlock, 0, st>>>(d, k)));
+            LG_DISPATCH(s, (k_lg_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
         }
     }
-    LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<nb, kBlock, 0, st>>>(d)));
+    LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<gtile, kBlock, 0, st>>>(d)));
     if (d.eb) {
-        LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 1><<<nb, kBlock, 0, st>>>(d, d.T)));
-        LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 1><<<nb, kBlock, 0, st>>>(d, d.T)));
-        k_lg_force_move<<<1, 64, 0, st>>>(d);
-        k_lg_path<<<gpath > (d.T + 64) / 64 ? gpath : (d.T + 64) / 64, 64, 0, st>>>(d, 1);
+        LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 1><<<gtile, kBlock, 0, st>>>(d, d.T)));
+        LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 1><<<gtile, kBlock, 0, st>>>(d, d.T)));
+        k_lg_force_move<<<gone, 64, 0, st>>>(d);
+        k_lg_path<<<dim3(gpath > (d.T + 64) / 64 ? gpath : (d.T + 64) / 64, d.C), 64, 0, st>>>(d, 1);
     } else {
-        LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 2><<<nb, kBlock, 0, st>>>(d, d.T)));
-        LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 2><<<nb, kBlock, 0, st>>>(d, d.T)));
-        k_lg_backscan<<<1, 256, 0, st>>>(d);
+        LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 2><<<gtile, kBlock, 0, st>>>(d, d.T)));
+        LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 2><<<gtile, kBlock, 0, st>>>(d, d.T)));
+        k_lg_backscan<<<gone, 256, 0, st>>>(d);
     }
     {
         const int64_t n = (int64_t)d.N * d.du;
         int g = (int)((n + 255) / 256);
         g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
-        k_lg_export<<<g, 256, 0, st>>>(d);
+        k_lg_export<<<dim3(g, d.C), 256, 0, st>>>(d);
     }
-    if (chain) k_lg_advance<<<1, 256, 0, st>>>(d);
+    if (chain) {
+        k_lg_advance<<<gone, 256, 0, st>>>(d);
+        k_lg_advance_key<<<1, 64, 0, st>>>(d);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("sweep launch: ") + hipGetErrorString(e));
     return FBSMI_OK;
@@ -847,8 +924,8 @@ int collect_profile(fbsmi_lg_sweep* s) {
 extern "C" {
 
 int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int explicit_backward, int explicit_final,
-                          int store_path, fbsmi_lg_sweep** out) {
-    if (!m || !out || nparticles < 1 || m->du < 1 || m->dv < 1 || m->T < 1)
+                          int store_path, int32_t nchains, fbsmi_lg_sweep** out) {
+    if (!m || !out || nparticles < 1 || m->du < 1 || m->dv < 1 || m->T < 1 || nchains < 1 || nchains > 65535)
         return fail(FBSMI_ERR_ARG, "lg_sweep_create: bad arguments");
     if (!m->G || !m->g || !m->sd || !m->lognorm || !m->F || !m->sqQ)
         return fail(FBSMI_ERR_ARG, "lg_sweep_create: null model table");
@@ -860,6 +937,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     fbsmi_lg_sweep* s = new (std::nothrow) fbsmi_lg_sweep();
     if (!s) return fail(FBSMI_ERR_ARG, "out of host memory");
     LgDev& d = s->d;
+    d.C = nchains;
     d.nparticles = nparticles;
     d.N = explicit_final ? nparticles + 1 : nparticles;
     d.du = m->du;
@@ -884,48 +962,49 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: more than 4M particles per device not supported yet");
     }
     if (store_path) {
-        const double bytes = ((double)d.T * d.N * 4.0) + ((double)(d.T + 1) * d.N * (d.du + 1) * 4.0);
+        const double bytes = (((double)d.T * d.N * 4.0) + ((double)(d.T + 1) * d.N * (d.du + 1) * 4.0)) * nchains;
         if (bytes > 200e9) {
             delete s;
             return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: path storage (T,N,du) does not fit device memory");
         }
     }
-    const size_t N = d.N, T = d.T;
+    const size_t N = d.N, T = d.T, C = nchains;
     int rc = 0;
     rc |= dev_alloc(s, &d.key, 2);
-    rc |= dev_alloc(s, &d.x0, d.du);
+    rc |= dev_alloc(s, &d.keys, 2 * C);
+    rc |= dev_alloc(s, &d.x0, C * d.du);
     rc |= dev_alloc(s, &d.y0, d.dv);
-    rc |= dev_alloc(s, &d.bs, T + 1);
-    rc |= dev_alloc(s, &d.keytab, 8 * T);
-    rc |= dev_alloc(s, &d.misc, 16);
-    rc |= dev_alloc(s, &d.xi1, T * D);
-    rc |= dev_alloc(s, &d.xi2, T * D);
-    rc |= dev_alloc(s, &d.path, (T + 1) * D);
-    rc |= dev_alloc(s, &d.us_star, (T + 1) * d.du);
-    rc |= dev_alloc(s, &d.vs, (T + 1) * d.dv);
-    rc |= dev_alloc(s, &d.u0, N * d.du);
-    rc |= dev_alloc(s, &d.u1, N * d.du);
-    rc |= dev_alloc(s, &d.lw, N);
-    rc |= dev_alloc(s, &d.lwn, N);
-    rc |= dev_alloc(s, &d.w, N);
-    rc |= dev_alloc(s, &d.cdf, N);
-    rc |= dev_alloc(s, &d.cdfJ, N);
-    rc |= dev_alloc(s, &d.bmax, d.nb);
-    rc |= dev_alloc(s, &d.bsumexp, d.nb);
-    rc |= dev_alloc(s, &d.bsumw, d.nb);
-    rc |= dev_alloc(s, &d.bsumJ, d.nb);
-    rc |= dev_alloc(s, &d.scal, 16);
-    rc |= dev_alloc(s, &d.usT, N * d.du);
-    rc |= dev_alloc(s, &d.x0n, d.du);
-    rc |= dev_alloc(s, &d.usn, (T + 1) * d.du);
-    rc |= dev_alloc(s, &d.bsn, T + 1);
-    rc |= dev_alloc(s, &d.acc, T + 1);
+    rc |= dev_alloc(s, &d.bs, C * (T + 1));
+    rc |= dev_alloc(s, &d.keytab, C * 8 * T);
+    rc |= dev_alloc(s, &d.misc, C * 16);
+    rc |= dev_alloc(s, &d.xi1, C * T * D);
+    rc |= dev_alloc(s, &d.xi2, C * T * D);
+    rc |= dev_alloc(s, &d.path, 1);
+    rc |= dev_alloc(s, &d.us_star, C * (T + 1) * d.du);
+    rc |= dev_alloc(s, &d.vs, C * (T + 1) * d.dv);
+    rc |= dev_alloc(s, &d.u0, C * N * d.du);
+    rc |= dev_alloc(s, &d.u1, C * N * d.du);
+    rc |= dev_alloc(s, &d.lw, C * N);
+    rc |= dev_alloc(s, &d.lwn, C * N);
+    rc |= dev_alloc(s, &d.w, C * N);
+    rc |= dev_alloc(s, &d.cdf, C * N);
+    rc |= dev_alloc(s, &d.cdfJ, C * N);
+    rc |= dev_alloc(s, &d.bmax, C * d.nb);
+    rc |= dev_alloc(s, &d.bsumexp, C * d.nb);
+    rc |= dev_alloc(s, &d.bsumw, C * d.nb);
+    rc |= dev_alloc(s, &d.bsumJ, C * d.nb);
+    rc |= dev_alloc(s, &d.scal, C * 16);
+    rc |= dev_alloc(s, &d.usT, C * N * d.du);
+    rc |= dev_alloc(s, &d.x0n, C * d.du);
+    rc |= dev_alloc(s, &d.usn, C * (T + 1) * d.du);
+    rc |= dev_alloc(s, &d.bsn, C * (T + 1));
+    rc |= dev_alloc(s, &d.acc, C * (T + 1));
     rc |= dev_alloc(s, &d.x0s_slot, 1);
     rc |= dev_alloc(s, &d.counter, 1);
     if (store_path) {
-        rc |= dev_alloc(s, &d.As, T * N);
-        rc |= dev_alloc(s, &d.uss, (T + 1) * N * d.du);
-        rc |= dev_alloc(s, &d.lwss, (T + 1) * N);
+        rc |= dev_alloc(s, &d.As, C * T * N);
+        rc |= dev_alloc(s, &d.uss, C * (T + 1) * N * d.du);
+        rc |= dev_alloc(s, &d.lwss, C * (T + 1) * N);
     }
     if (rc) {
         fbsmi_lg_sweep_destroy(s);
@@ -955,26 +1034,27 @@ void fbsmi_lg_sweep_destroy(fbsmi_lg_sweep* s) {
     delete s;
 }
 
-int fbsmi_lg_gibbs_sweep(fbsmi_lg_sweep* s, const uint32_t* key, const float* x0, const float* y0,
+int fbsmi_lg_gibbs_sweep(fbsmi_lg_sweep* s, const uint32_t* keys, const float* x0, const float* y0,
                          const int32_t* bs_star, float* x0_next, float* us_star_next, int32_t* bs_next,
                          uint8_t* acc, int use_graph, void* stream) {
-    if (!s || !key || !x0 || !y0 || !bs_star) return fail(FBSMI_ERR_ARG, "lg_gibbs_sweep: null input");
+    if (!s || !keys || !x0 || !y0 || !bs_star) return fail(FBSMI_ERR_ARG, "lg_gibbs_sweep: null input");
     hipStream_t ust = (hipStream_t)stream;
     const LgDev& d = s->d;
+    const size_t C = d.C, T1 = d.T + 1;
     FBSMI_HIP_TRY(hipEventRecord(s->ev_in, ust));
     FBSMI_HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_in, 0));
-    FBSMI_HIP_TRY(hipMemcpyAsync(d.key, key, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
-    FBSMI_HIP_TRY(hipMemcpyAsync(d.x0, x0, d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.keys, keys, C * 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.x0, x0, C * d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     FBSMI_HIP_TRY(hipMemcpyAsync(d.y0, y0, d.dv * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-    FBSMI_HIP_TRY(hipMemcpyAsync(d.bs, bs_star, (d.T + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.bs, bs_star, C * T1 * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
     int rc = run_sweep(s, 0, use_graph);
     if (rc) return rc;
-    if (x0_next) FBSMI_HIP_TRY(hipMemcpyAsync(x0_next, d.x0n, d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    if (x0_next) FBSMI_HIP_TRY(hipMemcpyAsync(x0_next, d.x0n, C * d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     if (us_star_next)
-        FBSMI_HIP_TRY(hipMemcpyAsync(us_star_next, d.usn, (size_t)(d.T + 1) * d.du * sizeof(float),
-                                     hipMemcpyDeviceToDevice, s->stream));
-    if (bs_next) FBSMI_HIP_TRY(hipMemcpyAsync(bs_next, d.bsn, (d.T + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
-    if (acc) FBSMI_HIP_TRY(hipMemcpyAsync(acc, d.acc, (d.T + 1), hipMemcpyDeviceToDevice, s->stream));
+        FBSMI_HIP_TRY(hipMemcpyAsync(us_star_next, d.usn, C * T1 * d.du * sizeof(float), hipMemcpyDeviceToDevice,
+                                     s->stream));
+    if (bs_next) FBSMI_HIP_TRY(hipMemcpyAsync(bs_next, d.bsn, C * T1 * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+    if (acc) FBSMI_HIP_TRY(hipMemcpyAsync(acc, d.acc, C * T1, hipMemcpyDeviceToDevice, s->stream));
     rc = collect_profile(s);
     if (rc) return rc;
     FBSMI_HIP_TRY(hipEventRecord(s->ev_out, s->stream));
@@ -987,12 +1067,13 @@ int fbsmi_lg_gibbs_chain(fbsmi_lg_sweep* s, uint32_t* key, float* x0, const floa
     if (!s || !key || !x0 || !y0 || !bs_star || nsweeps < 0) return fail(FBSMI_ERR_ARG, "lg_gibbs_chain: bad arguments");
     hipStream_t ust = (hipStream_t)stream;
     const LgDev& d = s->d;
+    const size_t C = d.C, T1 = d.T + 1;
     FBSMI_HIP_TRY(hipEventRecord(s->ev_in, ust));
     FBSMI_HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_in, 0));
     FBSMI_HIP_TRY(hipMemcpyAsync(d.key, key, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
-    FBSMI_HIP_TRY(hipMemcpyAsync(d.x0, x0, d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.x0, x0, C * d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     FBSMI_HIP_TRY(hipMemcpyAsync(d.y0, y0, d.dv * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-    FBSMI_HIP_TRY(hipMemcpyAsync(d.bs, bs_star, (d.T + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.bs, bs_star, C * T1 * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
     FBSMI_HIP_TRY(hipMemsetAsync(d.counter, 0, sizeof(int32_t), s->stream));
     FBSMI_HIP_TRY(hipMemcpyAsync(d.x0s_slot, &x0s, sizeof(float*), hipMemcpyHostToDevice, s->stream));
     // the slot copy reads a host stack variable: make sure it has landed before we return
@@ -1002,8 +1083,8 @@ int fbsmi_lg_gibbs_chain(fbsmi_lg_sweep* s, uint32_t* key, float* x0, const floa
         if (rc) return rc;
     }
     FBSMI_HIP_TRY(hipMemcpyAsync(key, d.key, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
-    FBSMI_HIP_TRY(hipMemcpyAsync(x0, d.x0, d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-    FBSMI_HIP_TRY(hipMemcpyAsync(bs_star, d.bs, (d.T + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(x0, d.x0, C * d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(bs_star, d.bs, C * T1 * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
     int rc = collect_profile(s);
     if (rc) return rc;
     FBSMI_HIP_TRY(hipEventRecord(s->ev_out, s->stream));
@@ -1018,13 +1099,13 @@ int fbsmi_lg_sweep_view(fbsmi_lg_sweep* s, int which, void* dst, int64_t* count,
     int64_t n = 0;
     size_t esz = 4;
     switch (which) {
-        case 0: src = d.usT; n = (int64_t)d.N * d.du; break;
-        case 1: src = d.lwn; n = d.N; break;
-        case 2: src = d.As; n = (int64_t)d.T * d.N; break;
-        case 3: src = d.uss; n = (int64_t)(d.T + 1) * d.N * d.du; break;
-        case 4: src = d.lwss; n = (int64_t)(d.T + 1) * d.N; break;
-        case 5: src = d.us_star; n = (int64_t)(d.T + 1) * d.du; break;
-        case 6: src = d.vs; n = (int64_t)(d.T + 1) * d.dv; break;
+        case 0: src = d.usT; n = (int64_t)d.C * d.N * d.du; break;
+        case 1: src = d.lwn; n = (int64_t)d.C * d.N; break;
+        case 2: src = d.As; n = (int64_t)d.C * d.T * d.N; break;
+        case 3: src = d.uss; n = (int64_t)d.C * (d.T + 1) * d.N * d.du; break;
+        case 4: src = d.lwss; n = (int64_t)d.C * (d.T + 1) * d.N; break;
+        case 5: src = d.us_star; n = (int64_t)d.C * (d.T + 1) * d.du; break;
+        case 6: src = d.vs; n = (int64_t)d.C * (d.T + 1) * d.dv; break;
         default: return fail(FBSMI_ERR_ARG, "lg_sweep_view: unknown view");
     }
     if (!src) n = 0;

@@ -177,9 +177,10 @@ class LinearGaussianBridge:
         return self._t(m_) + z @ self._t(chol)
 
     # -- fused engine ----------------------------------------------------------------------------
-    def sweep_handle(self, nparticles: int, explicit_backward=True, explicit_final=False, store_path=None):
+    def sweep_handle(self, nparticles: int, explicit_backward=True, explicit_final=False, store_path=None,
+                     nchains: int = 1):
         store = (not explicit_backward) if store_path is None else bool(store_path)
-        keyt = (int(nparticles), bool(explicit_backward), bool(explicit_final), store)
+        keyt = (int(nparticles), bool(explicit_backward), bool(explicit_final), store, int(nchains))
         h = self._sweeps.get(keyt)
         if h is None:
             h = LGSweep(self, *keyt)
@@ -194,19 +195,21 @@ class LinearGaussianBridge:
 
 
 class LGSweep:
-    """Owns one fbsmi_lg_sweep handle (device buffers + captured hipGraph)."""
+    """Owns one fbsmi_lg_sweep handle (device buffers + captured hipGraph) for `nchains` chains.
 
-    def __init__(self, model: LinearGaussianBridge, nparticles, eb, ef, store):
+    With nchains == 1 the chain axis is squeezed from inputs and outputs (the reference's plain
+    gibbs_kernel); with nchains > 1 every per-chain array carries a leading axis of that size, like
+    the reference's jax.vmap(gibbs_kernel, in_axes=[0, 0, None, 0, 0]) (gp_gibbs.py:173)."""
+
+    def __init__(self, model: LinearGaussianBridge, nparticles, eb, ef, store, nchains=1):
         self.model = model
-        self.nparticles, self.eb, self.ef, self.store = nparticles, eb, ef, store
+        self.nparticles, self.eb, self.ef, self.store, self.C = nparticles, eb, ef, store, int(nchains)
         h = C.c_void_p()
         with torch.cuda.device(model.device):
             _lib.call("fbsmi_lg_sweep_create", C.byref(model.struct), nparticles, int(eb), int(ef), int(store),
-                      C.byref(h))
+                      self.C, C.byref(h))
         self.h = h
         self.n_rows = nparticles + 1 if ef else nparticles
-        dev = model.device
-        self._key = torch.zeros(2, dtype=torch.int32, device=dev)
 
     def __del__(self):
         try:
@@ -221,42 +224,49 @@ class LGSweep:
             x = torch.as_tensor(np.asarray(x))
         return x.to(self.model.device, dtype).contiguous().reshape(shape)
 
-    def _key_t(self, key):
-        k = np.asarray(key.detach().cpu() if isinstance(key, torch.Tensor) else key).astype(np.uint32).reshape(2)
+    def _key_t(self, key, n):
+        k = np.asarray(key.detach().cpu() if isinstance(key, torch.Tensor) else key).astype(np.uint32).reshape(n, 2)
         return torch.from_numpy(k.view(np.int32).copy()).to(self.model.device)
 
+    def _sq(self, t):
+        return t[0] if self.C == 1 else t
+
     def sweep(self, key, x0, y0, bs_star, use_graph=True):
-        m = self.model
-        kt = self._key_t(key)
-        x0t = self._dev(x0, torch.float32, (m.du,))
+        """key (C,2) [or (2,)], x0 (C,du), y0 (dv,), bs_star (C,T+1) -> (x0, us_star, bs_star, acc)."""
+        m, Cn = self.model, self.C
+        kt = self._key_t(key, Cn)
+        x0t = self._dev(x0, torch.float32, (Cn, m.du))
         y0t = self._dev(y0, torch.float32, (m.dv,))
-        bst = self._dev(bs_star, torch.int32, (m.T + 1,))
-        x0n = torch.empty(m.du, dtype=torch.float32, device=m.device)
-        usn = torch.empty((m.T + 1, m.du), dtype=torch.float32, device=m.device)
-        bsn = torch.empty(m.T + 1, dtype=torch.int32, device=m.device)
-        acc = torch.empty(m.T + 1, dtype=torch.uint8, device=m.device)
+        bst = self._dev(bs_star, torch.int32, (Cn, m.T + 1))
+        x0n = torch.empty((Cn, m.du), dtype=torch.float32, device=m.device)
+        usn = torch.empty((Cn, m.T + 1, m.du), dtype=torch.float32, device=m.device)
+        bsn = torch.empty((Cn, m.T + 1), dtype=torch.int32, device=m.device)
+        acc = torch.empty((Cn, m.T + 1), dtype=torch.uint8, device=m.device)
         _lib.call("fbsmi_lg_gibbs_sweep", self.h, kt.data_ptr(), x0t.data_ptr(), y0t.data_ptr(), bst.data_ptr(),
                   x0n.data_ptr(), usn.data_ptr(), bsn.data_ptr(), acc.data_ptr(), int(bool(use_graph)), ops._stream())
-        return x0n, usn, bsn, acc.bool()
+        return self._sq(x0n), self._sq(usn), self._sq(bsn), self._sq(acc.bool())
 
     def chain(self, key, x0, y0, bs_star, nsweeps, keep=True, use_graph=True):
-        """nsweeps sweeps with ``key, subkey = split(key)`` per sweep (tests/test_gibbs.py:115-118).
-        Returns (key, x0, bs_star, x0s)."""
-        m = self.model
-        kt = self._key_t(key)
-        x0t = self._dev(x0, torch.float32, (m.du,)).clone()
+        """nsweeps sweeps; per sweep ``key, subkey = split(key)``; one chain sweeps with subkey
+        (tests/test_gibbs.py:115-118), C > 1 chains with split(subkey, C)[c] (gp_gibbs.py:183-185).
+        Returns (key, x0, bs_star, x0s) with x0s of shape (nsweeps, [C,] du)."""
+        m, Cn = self.model, self.C
+        kt = self._key_t(key, 1)
+        x0t = self._dev(x0, torch.float32, (Cn, m.du)).clone()
         y0t = self._dev(y0, torch.float32, (m.dv,))
-        bst = self._dev(bs_star, torch.int32, (m.T + 1,)).clone()
-        x0s = torch.empty((nsweeps, m.du), dtype=torch.float32, device=m.device) if keep else None
+        bst = self._dev(bs_star, torch.int32, (Cn, m.T + 1)).clone()
+        x0s = torch.empty((nsweeps, Cn, m.du), dtype=torch.float32, device=m.device) if keep else None
         _lib.call("fbsmi_lg_gibbs_chain", self.h, kt.data_ptr(), x0t.data_ptr(), y0t.data_ptr(), bst.data_ptr(),
                   int(nsweeps), x0s.data_ptr() if keep else None, int(bool(use_graph)), ops._stream())
-        key_out = kt.cpu().numpy().view(np.uint32).copy()
-        return key_out, x0t, bst, x0s
+        key_out = kt.cpu().numpy().view(np.uint32).reshape(2).copy()
+        if keep and Cn == 1:
+            x0s = x0s[:, 0]
+        return key_out, self._sq(x0t), self._sq(bst), x0s
 
     def views(self):
-        """Parity views of the last sweep's CSMC forward pass (copies)."""
+        """Parity views of the last sweep's CSMC forward pass (copies; leading chain axis if C > 1)."""
         m = self.model
-        N = self.n_rows
+        N, Cn = self.n_rows, self.C
         spec = {"us_T": (0, torch.float32, (N, m.du)), "lw_T": (1, torch.float32, (N,)),
                 "As": (2, torch.int32, (m.T, N)), "uss": (3, torch.float32, (m.T + 1, N, m.du)),
                 "log_wss": (4, torch.float32, (m.T + 1, N)), "us_star": (5, torch.float32, (m.T + 1, m.du)),
@@ -270,7 +280,7 @@ class LGSweep:
                 continue
             buf = torch.empty(cnt.value, dtype=dtype, device=m.device)
             _lib.call("fbsmi_lg_sweep_view", self.h, which, buf.data_ptr(), C.byref(cnt), ops._stream())
-            out[name] = buf.reshape(shape)
+            out[name] = self._sq(buf.reshape((Cn,) + shape))
         return out
 
     def profile(self, enable: bool):

@@ -133,27 +133,31 @@ int fbsmi_lg_transition_logpdf(const fbsmi_lg_model* m, int32_t k, float sd_k, f
 typedef struct fbsmi_lg_sweep fbsmi_lg_sweep; /* opaque: device buffers + captured hipGraph */
 
 /* Create the state for gibbs_kernel sweeps (fbs/samplers/gibbs.py:68-168, marg_y=False) with
- * `nparticles` particles.  store_path != 0 keeps As / uss / log_wss (needed when
- * explicit_backward == 0).  Allocates device memory (not stream-ordered; call once). */
+ * `nparticles` particles, for `nchains` independent chains batched in every launch -- the
+ * reference's jax.vmap over chains (experiments/toy/gp_gibbs.py:25,172-173).  store_path != 0 keeps
+ * As / uss / log_wss (needed when explicit_backward == 0).  Allocates device memory (not
+ * stream-ordered; call once).  All per-chain arrays below are laid out [nchains][...]. */
 int fbsmi_lg_sweep_create(const fbsmi_lg_model* model, int32_t nparticles, int explicit_backward,
-                          int explicit_final, int store_path, fbsmi_lg_sweep** out);
+                          int explicit_final, int store_path, int32_t nchains, fbsmi_lg_sweep** out);
 void fbsmi_lg_sweep_destroy(fbsmi_lg_sweep* s);
-/* One Gibbs sweep, everything on the device.  key (2 x uint32), x0 (du), y0 (dv), bs_star (T+1)
- * are device inputs; x0_next (du), us_star_next (T+1,du), bs_next (T+1), acc (T+1 bytes) device
- * outputs (may alias the inputs of the next call).  use_graph != 0 replays a hipGraph captured on
- * the first call.  */
-int fbsmi_lg_gibbs_sweep(fbsmi_lg_sweep* s, const uint32_t* key, const float* x0, const float* y0,
+/* One Gibbs sweep of every chain, everything on the device.  keys (C,2) uint32, x0 (C,du),
+ * y0 (dv) shared, bs_star (C,T+1) are device inputs; x0_next (C,du), us_star_next (C,T+1,du),
+ * bs_next (C,T+1), acc (C,T+1) bytes are device outputs (nullable; may alias the inputs of the next
+ * call).  use_graph != 0 replays a hipGraph captured on the first call. */
+int fbsmi_lg_gibbs_sweep(fbsmi_lg_sweep* s, const uint32_t* keys, const float* x0, const float* y0,
                          const int32_t* bs_star, float* x0_next, float* us_star_next, int32_t* bs_next,
                          uint8_t* acc, int use_graph, void* stream);
-/* Chain `nsweeps` sweeps with the key schedule of the reference's drivers
- * (key, subkey = split(key); sweep(subkey): tests/test_gibbs.py:115-118).  key / x0 / bs_star are
- * updated in place; x0s (nullable) receives (nsweeps, du). */
+/* Chain `nsweeps` sweeps with the key schedule of the reference's drivers: per sweep
+ * key, subkey = split(key); one chain sweeps with subkey (tests/test_gibbs.py:115-118), a batch of
+ * C > 1 chains with split(subkey, C)[c] (experiments/toy/gp_gibbs.py:183-185).  key (2), x0 (C,du),
+ * bs_star (C,T+1) are updated in place; x0s (nullable) receives (nsweeps, C, du). */
 int fbsmi_lg_gibbs_chain(fbsmi_lg_sweep* s, uint32_t* key, float* x0, const float* y0, int32_t* bs_star,
                          int32_t nsweeps, float* x0s, int use_graph, void* stream);
 /* Parity views of the last sweep: copies view `which` into dst (device, nullable) and reports its
  * element count.  which: 0 final particles (n,du) row-major, 1 final normalised log-weights (n),
  * 2 As (T,n) int32, 3 uss (T+1,n,du), 4 log_wss (T+1,n) [2-4 only with store_path],
- * 5 us_star (T+1,du) and 6 vs (T+1,dv) of the sweep.  n = nparticles (+1 if explicit_final). */
+ * 5 us_star (T+1,du) and 6 vs (T+1,dv) of the sweep; each with a leading [nchains] axis.
+ * n = nparticles (+1 if explicit_final). */
 int fbsmi_lg_sweep_view(fbsmi_lg_sweep* s, int which, void* dst, int64_t* count, void* stream);
 /* HIP-event timing hooks: average duration in microseconds of the propagate ("Euler") kernel
  * over the launches since the last reset; 0 launches -> returns 0. Only measured when

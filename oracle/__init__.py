@@ -479,6 +479,27 @@ def gibbs_chain_lg(m: LGModel, key, x0, y0, bs_star, nparticles, nsweeps, explic
     return key, x0, bs, x0s
 
 
+def gibbs_chains_lg(m: LGModel, key, x0s, y0, bs_stars, nparticles, nsweeps, explicit_backward=True,
+                    explicit_final=False):
+    """C chains driven like experiments/toy/gp_gibbs.py:182-187: per sweep key, subkey = split(key);
+    key_chains = split(subkey, C); chain c runs gibbs_kernel(key_chains[c], x0s[c], y0, _, bs_stars[c]).
+    Returns (key, x0s (C,du), bs_stars (C,T+1), samples (nsweeps,C,du))."""
+    key = _key(key).copy()
+    x0s = _f32(x0s).reshape(-1, m.du).copy()
+    bss = _i32(bs_stars).reshape(-1, m.T + 1).copy()
+    Cn = x0s.shape[0]
+    out = np.zeros((nsweeps, Cn, m.du), np.float32)
+    for i in range(nsweeps):
+        key, subkey = split(key, 2)
+        kc = split(subkey, Cn)
+        for c in range(Cn):
+            x0n, _, bsn, _ = gibbs_kernel_lg(m, kc[c], x0s[c], y0, bss[c], nparticles, explicit_backward,
+                                              explicit_final)
+            x0s[c], bss[c] = x0n, bsn
+        out[i] = x0s
+    return key, x0s, bss, out
+
+
 _RES = {"stratified": 0, "systematic": 1, "multinomial": 2, "killing": 3}
 
 

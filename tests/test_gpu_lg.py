@@ -188,6 +188,38 @@ def test_chain_and_closed_form_posterior(oracle, dev):
     np.testing.assert_allclose(xs.var(), 1.68, rtol=2e-2)       # test_gibbs.py:123
 
 
+@pytest.mark.parametrize("toy,C,N,T", [(toy_2d, 4, 100, 30), (toy_4d, 3, 300, 12), (toy_2d, 2, 1024, 20)])
+def test_batched_chains_match_oracle(toy, C, N, T, oracle, dev):
+    """nchains > 1: the reference's jax.vmap over chains (gp_gibbs.py:172-187), one launch sequence."""
+    toy = toy()
+    ts = np.linspace(0, 1, T + 1)
+    br = _bridge(toy, ts, dev)
+    om = oracle_model_from(oracle, br)
+    rng = np.random.default_rng(C * N)
+    x0 = rng.normal(size=(C, br.du)).astype(np.float32)
+    bs = rng.integers(0, N, (C, T + 1)).astype(np.int32)
+    sweep = br.sweep_handle(N, True, False, nchains=C)
+    # single batched sweep with explicit per-chain keys
+    keys = oracle.split(oracle.PRNGKey(5), C)
+    got = sweep.sweep(keys, x0, toy["y0"], bs)
+    v = sweep.views()
+    for c in range(C):
+        want = oracle.gibbs_kernel_lg(om, keys[c], x0[c], toy["y0"], bs[c], N, True, False, debug=True)
+        _eq(_np(got[0][c]), want[0], f"x0 chain {c}")
+        _eq(_np(got[1][c]), want[1], f"us_star chain {c}")
+        _eq(_np(got[2][c]), want[2], f"bs chain {c}")
+        _eq(_np(got[3][c]), want[3], f"acc chain {c}")
+        _eq(_np(v["us_T"][c]), want[4], f"particles chain {c}")
+        _eq(_np(v["lw_T"][c]), want[5], f"log-weights chain {c}")
+    # chained sweeps with the gp_gibbs key schedule
+    nsw = 6
+    key, x0f, bsf, x0s = sweep.chain(oracle.PRNGKey(9), x0, toy["y0"], bs, nsw)
+    okey, ox0, obs, oout = oracle.gibbs_chains_lg(om, oracle.PRNGKey(9), x0, toy["y0"], bs, N, nsw)
+    np.testing.assert_array_equal(key, okey)
+    _eq(_np(x0s), oout, "chain samples")
+    _eq(_np(bsf), obs, "final bs_star")
+
+
 def test_baseline_config2_one_sweep(oracle, dev):
     """BASELINE config 2: N = 65 536, T = 500, ts = linspace(0, 2, 501)."""
     toy = toy_2d()

@@ -7,23 +7,23 @@
 #include <vector>
 #include "../include/fbsmi.h"
 int main(int argc, char** argv) {
-    const int N = argc > 1 ? atoi(argv[1]) : 65536, T = 500, D = 2;
+    const int N = argc > 1 ? atoi(argv[1]) : 65536, T = 500, D = 2, C = argc > 2 ? atoi(argv[2]) : 1;
     std::vector<float> G(T * D * D), g(T * D), sd(T), ln(T), F(T), sq(T);
     for (int k = 0; k < T; ++k) { G[k*4] = -0.3f; G[k*4+1] = 0.1f; G[k*4+2] = 0.1f; G[k*4+3] = -0.4f; g[k*2] = 0.1f; g[k*2+1] = -0.1f;
         sd[k] = 0.0632f; ln[k] = logf(6.2831853f * sd[k] * sd[k]); F[k] = 0.998f; sq[k] = 0.0632f; }
     auto up = [](const std::vector<float>& v) { float* p; (void)hipMalloc(&p, v.size() * 4); (void)hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice); return p; };
     fbsmi_lg_model m{1, 1, T, 2.0f / T, up(G), up(g), up(sd), up(ln), up(F), up(sq)};
     fbsmi_lg_sweep* s = nullptr;
-    if (fbsmi_lg_sweep_create(&m, N, 1, 0, 0, &s)) { printf("create failed: %s\n", fbsmi_last_error()); return 1; }
+    if (fbsmi_lg_sweep_create(&m, N, 1, 0, 0, C, &s)) { printf("create failed: %s\n", fbsmi_last_error()); return 1; }
     uint32_t* key; float *x0, *y0; int32_t* bs;
-    (void)hipMalloc(&key, 8); (void)hipMalloc(&x0, 4); (void)hipMalloc(&y0, 4); (void)hipMalloc(&bs, (T + 1) * 4);
-    (void)hipMemset(key, 1, 8); (void)hipMemset(x0, 0, 4); (void)hipMemset(y0, 0, 4); (void)hipMemset(bs, 0, (T + 1) * 4);
+    (void)hipMalloc(&key, 8); (void)hipMalloc(&x0, 4 * C); (void)hipMalloc(&y0, 4); (void)hipMalloc(&bs, (T + 1) * 4 * C);
+    (void)hipMemset(key, 1, 8); (void)hipMemset(x0, 0, 4 * C); (void)hipMemset(y0, 0, 4); (void)hipMemset(bs, 0, (T + 1) * 4 * C);
     hipStream_t st; (void)hipStreamCreate(&st);
     fbsmi_lg_gibbs_chain(s, key, x0, y0, bs, 2, nullptr, 1, st); (void)hipStreamSynchronize(st);
     auto t0 = std::chrono::steady_clock::now();
     fbsmi_lg_gibbs_chain(s, key, x0, y0, bs, 10, nullptr, 1, st); (void)hipStreamSynchronize(st);
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 10;
-    printf("bare C++ host, mask %s, N=%d: %.3f ms/sweep = %.2f us/step\n", getenv("FBSMI_DEBUG_STEP_MASK") ? getenv("FBSMI_DEBUG_STEP_MASK") : "15", N, dt * 1e3, dt / T * 1e6);
+    printf("bare C++ host, mask %s, N=%d, chains=%d: %.3f ms/sweep = %.2f us/step = %.3f G particle-steps/s\n", getenv("FBSMI_DEBUG_STEP_MASK") ? getenv("FBSMI_DEBUG_STEP_MASK") : "15", N, C, dt * 1e3, dt / T * 1e6, (double)N * T * C / dt / 1e9);
     fbsmi_lg_sweep_destroy(s);
     return 0;
 }
