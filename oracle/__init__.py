@@ -534,3 +534,105 @@ def bench_gibbs_lg(m: LGModel, seed, x0, y0, nparticles, nsweeps):
     lib().orc_bench_gibbs_lg(m.ref, int(seed), _f32(x0).reshape(m.du), _f32(y0).reshape(m.dv), int(nparticles),
                              int(nsweeps), out)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# numpy restatements of the remaining hot-path functions (composed from the C primitives above)
+# ------------------------------------------------------------------------------------------------
+def csmc_kernel_lg(m: LGModel, key, us_star, bs_star, vs, us0, lw0, backward=False):
+    """csmc_kernel (csmc.py:14-77) with killing resampling."""
+    key_fwd, key_bwd = split(key, 2)                                                # :65
+    fp = csmc_forward_pass_lg(m, key_fwd, us_star, bs_star, vs, us0, lw0, "killing")
+    if backward:
+        return backward_sampling_pass_lg(m, key_bwd, vs, fp["uss"], fp["log_wss"])  # :73
+    return backward_scanning_pass(key_bwd, fp["As"], fp["uss"], fp["log_wss"][-1])  # :75
+
+
+def pcn_proposal(key, delta, x, mean, sampler):
+    """smc.py:161-168 in float32."""
+    f = np.float32
+    beta = 2 / (2 + delta)
+    k = split(key, 2)
+    r0, r1 = sampler(k[0]), sampler(k[1])
+    p = x + f(np.sqrt(delta / 2)) * (r0 - mean)
+    return (f(beta) * p + f(1 - beta) * mean + f(np.sqrt(1 - beta)) * (r1 - mean)).astype(f)
+
+
+def lg_ref_sampler(m0, cov0, FQ_T, du, key, yT, n):
+    """ref_sampler of gp_pmcmc.py:130-133 / gp_gibbs.py:138-141: p(u0 | v0) at the terminal time."""
+    Ft, Qt = FQ_T
+    m0 = np.asarray(m0, np.float64)
+    D = m0.size
+    m_ref = Ft * m0
+    cov_ref = Ft ** 2 * np.asarray(cov0, np.float64) + Qt * np.eye(D)
+    gain = cov_ref[:du, du:] @ np.linalg.inv(cov_ref[du:, du:])
+    m_ = m_ref[:du] + gain @ (np.asarray(yT, np.float64).reshape(-1) - m_ref[du:])
+    cov_ = cov_ref[:du, :du] - gain @ cov_ref[du:, :du]
+    chol = np.linalg.cholesky(cov_)
+    z = normal(key, (n, du))
+    return (m_.astype(np.float32) + z @ chol.astype(np.float32)).astype(np.float32)
+
+
+def pmcmc_kernel_lg(m: LGModel, key, uT, log_ell, ys, y0, nparticles, ref_sampler, mean_path=None, delta=None,
+                    which_u=0, resampling="stratified"):
+    """pmcmc_kernel (smc.py:171-258) with the LG closures.  ys, mean_path: (T+1, dv)."""
+    f = np.float32
+    key_prop, key_u0, key_filter, key_mh = split(key, 4)                           # :231
+    fwd_ys = lambda k: lg_fwd_sampler(m, k, _f32(y0).reshape(-1))
+    if delta is None:
+        prop_ys = fwd_ys(key_prop)
+    else:
+        prop_ys = pcn_proposal(key_prop, delta, _f32(ys), _f32(mean_path), fwd_ys)  # :237
+    vs = prop_ys[::-1].copy()                                                        # :239
+    u0s = ref_sampler(key_u0, vs[0], nparticles)                                     # :241
+    prop_uTs, prop_log_ell = pmcmc_filter_step_lg(m, key_filter, vs, u0s, resampling)  # :242
+    prop_uT = prop_uTs[which_u]
+    log_acc = np.minimum(f(0.0), f(prop_log_ell) - f(log_ell))                       # :246
+    z = uniform(key_mh, ())                                                          # :248
+    acc = bool(log(np.array([z], f))[0] < log_acc)                                   # :249
+    if acc:
+        return prop_uT, f(prop_log_ell), prop_ys, acc
+    return _f32(uT), f(log_ell), _f32(ys), acc
+
+
+def euler_maruyama_np(key, x0, ts, drift, dispersion, integration_nsteps=1, return_path=False):
+    """fbs/sdes/simulators.py:53-106 in float32 numpy (drift / dispersion: python callables)."""
+    f = np.float32
+    ts = np.asarray(ts, np.float64)
+    n = ts.size - 1
+    keys = split(key, n)
+    x = _f32(x0).copy()
+    path = [x.copy()]
+    for k in range(n):
+        t, t_next = float(ts[k]), float(ts[k + 1])
+        ddt = abs(t_next - t) / integration_nsteps
+        rnds = normal(keys[k], (integration_nsteps,) + x.shape)
+        for j, t_ in enumerate(np.linspace(t, t_next - ddt, integration_nsteps)):
+            x = (x + drift(x, float(t_)) * f(ddt) + f(dispersion(float(t_)) * float(np.sqrt(ddt))) * rnds[j]).astype(f)
+        path.append(x.copy())
+    return np.stack(path) if return_path else x
+
+
+def doob_bridge_np(key, A, B, S, ddt, x0, xT, T, nsub, replace):
+    """doob_bridge_simulator (simulators.py:126-160) for an affine bridge drift A x + B xT, given the
+    float32 coefficient tables the product feeds its kernel (so the comparison isolates the kernel)."""
+    f = np.float32
+    keys = split(key, T)
+    x = _f32(x0).reshape(-1).copy()
+    tg = _f32(xT).reshape(-1)
+    D = x.size
+    out = [x.copy()]
+    A, B, S, ddt = _f32(A), _f32(B), _f32(S), _f32(ddt)
+    for k in range(T):
+        h = ddt[k]
+        sq = sqrt(np.array([h], f))[0]
+        xi = normal(keys[k], (nsub, D))
+        for j in range(nsub):
+            r = k * nsub + j
+            drift = (A[r] * x + B[r] * tg).astype(f)
+            x = ((x + drift * h).astype(f) + (f(S[r] * sq) * xi[j]).astype(f)).astype(f)
+        out.append(x.copy())
+    out = np.stack(out)
+    if replace:
+        out[-1] = tg
+    return out
