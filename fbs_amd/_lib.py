@@ -59,6 +59,7 @@ SIGNATURES = {
     "fbsmi_random_bits": (C.c_int, [_u32, _u32, _i64, _vp, _vp]),
     "fbsmi_uniform": (C.c_int, [_u32, _u32, _i64, _vp, _vp]),
     "fbsmi_normal": (C.c_int, [_u32, _u32, _i64, _vp, _vp]),
+    "fbsmi_random_range": (C.c_int, [C.c_int, _u32, _u32, _i64, _i64, _i64, _vp, _vp]),
     "fbsmi_randint": (C.c_int, [_u32, _u32, _i64, _i32, _i32, _vp, _vp]),
     "fbsmi_math_map": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp]),
     "fbsmi_workspace_bytes": (C.c_size_t, [_i64]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "fbsmi_linear_path": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
     "fbsmi_affine_em_path": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, C.c_int, _vp, _vp]),
     "fbsmi_lg_transition_sampler": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _u32, _u32, _i64, _vp, _vp]),
+    "fbsmi_lg_transition_sampler_rows": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _u32, _u32, _i64, _i64, _i64, _vp, _vp]),
     "fbsmi_lg_likelihood_logpdf": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _vp, _i64, _vp, _vp]),
     "fbsmi_lg_transition_logpdf": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _vp, _i64, _vp, _vp]),
     "fbsmi_lg_sweep_create": (C.c_int, [C.POINTER(LGModelStruct), _i32, C.c_int, C.c_int, C.c_int, _i32, C.POINTER(_vp)]),

@@ -487,6 +487,86 @@ __device__ __forceinline__ int bisect_heap(const float* __restrict__ a, int n, i
     return hi;
 }
 
+// The same bisection as a resumable cursor, so that two independent searches can share their
+// memory round trips (issue both probe sets, wait once, apply both).
+struct BisectCursor {
+    int lo, hi;
+};
+
+struct BisectProbe {
+    int m1, m2l, m2r, m3a, m3b, m3c, m3d;
+    float v1, v2l, v2r, v3a, v3b, v3c, v3d;
+};
+
+__device__ __forceinline__ BisectCursor bisect_heap_levels(int n, int levels, const float* heap, float q) {
+    int lo = 0, hi = n, t = 1;
+    const int Lh = levels < kHeapLevels ? levels : kHeapLevels;
+    for (int l = 0; l < Lh; ++l) {
+        const int mid = (lo + hi) >> 1;
+        const bool gl = q <= heap[t];
+        hi = gl ? mid : hi;
+        lo = gl ? lo : mid;
+        t = 2 * t + (gl ? 0 : 1);
+    }
+    return BisectCursor{lo, hi};
+}
+
+// two searches walking the LDS levels in lockstep (their LDS reads overlap)
+__device__ __forceinline__ void bisect_heap_levels2(int n, int levels, const float* heapA, float qA,
+                                                    const float* heapB, float qB, BisectCursor& cA,
+                                                    BisectCursor& cB) {
+    int loA = 0, hiA = n, tA = 1, loB = 0, hiB = n, tB = 1;
+    const int Lh = levels < kHeapLevels ? levels : kHeapLevels;
+    for (int l = 0; l < Lh; ++l) {
+        const float hA = heapA[tA], hB = heapB[tB];
+        const int midA = (loA + hiA) >> 1, midB = (loB + hiB) >> 1;
+        const bool gA = qA <= hA, gB = qB <= hB;
+        hiA = gA ? midA : hiA;
+        loA = gA ? loA : midA;
+        tA = 2 * tA + (gA ? 0 : 1);
+        hiB = gB ? midB : hiB;
+        loB = gB ? loB : midB;
+        tB = 2 * tB + (gB ? 0 : 1);
+    }
+    cA = BisectCursor{loA, hiA};
+    cB = BisectCursor{loB, hiB};
+}
+
+__device__ __forceinline__ void bisect_issue(const float* __restrict__ a, const BisectCursor& c, BisectProbe& p) {
+    const int lo = c.lo, hi = c.hi;
+    p.m1 = (lo + hi) >> 1;
+    p.m2l = (lo + p.m1) >> 1;
+    p.m2r = (p.m1 + hi) >> 1;
+    p.m3a = (lo + p.m2l) >> 1;
+    p.m3b = (p.m2l + p.m1) >> 1;
+    p.m3c = (p.m1 + p.m2r) >> 1;
+    p.m3d = (p.m2r + hi) >> 1;
+    p.v1 = a[p.m1];
+    p.v2l = a[p.m2l];
+    p.v2r = a[p.m2r];
+    p.v3a = a[p.m3a];
+    p.v3b = a[p.m3b];
+    p.v3c = a[p.m3c];
+    p.v3d = a[p.m3d];
+}
+
+__device__ __forceinline__ void bisect_apply(BisectCursor& c, const BisectProbe& p, float q) {
+    int lo = c.lo, hi = c.hi;
+    const bool g1 = q <= p.v1;
+    hi = g1 ? p.m1 : hi;
+    lo = g1 ? lo : p.m1;
+    const int m2 = g1 ? p.m2l : p.m2r;
+    const bool g2 = q <= (g1 ? p.v2l : p.v2r);
+    hi = g2 ? m2 : hi;
+    lo = g2 ? lo : m2;
+    const int m3 = g1 ? (g2 ? p.m3a : p.m3b) : (g2 ? p.m3c : p.m3d);
+    const bool g3 = q <= (g1 ? (g2 ? p.v3a : p.v3b) : (g2 ? p.v3c : p.v3d));
+    hi = g3 ? m3 : hi;
+    lo = g3 ? lo : m3;
+    c.lo = lo;
+    c.hi = hi;
+}
+
 // logsumexp's "amax if finite else 0" (jax.scipy.special.logsumexp)
 __device__ __forceinline__ float finite_or_zero(float m) { return (fabsf(m) <= 3.40282347e+38f) ? m : 0.0f; }
 

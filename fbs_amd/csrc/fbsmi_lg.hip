@@ -83,7 +83,19 @@ struct LgDev {
     // chain bookkeeping
     float** x0s_slot;  // device slot holding the x0s pointer (or null)
     int32_t* counter;  // device sweep counter
+    unsigned long long* dbg;  // [64] in-kernel stamps (diagnostic build -DFBSMI_STAMPS only)
 };
+
+#ifdef FBSMI_STAMPS
+// diagnostic build: one lane of the middle workgroup records (100 MHz wall clock, shader clock)
+#define FBSMI_STAMP(i)                                                                   \
+    if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) {            \
+        d.dbg[2 * (i)] = __builtin_amdgcn_s_memrealtime();                               \
+        d.dbg[2 * (i) + 1] = __builtin_amdgcn_s_memtime();                               \
+    }
+#else
+#define FBSMI_STAMP(i)
+#endif
 
 // The view of chain c: every per-chain array advanced to that chain's slice (all per-chain arrays
 // are laid out [C][...]).
@@ -358,6 +370,7 @@ __device__ __forceinline__ float block_max4(float m, float* lds4) {  // lds4 unt
 template <int ITEMS>
 __global__ void __launch_bounds__(kBlock) k_lg_sumexp(LgDev dd) {
     const LgDev d = chain_view(dd, blockIdx.y);
+    FBSMI_STAMP(0)
     __shared__ float xch[2][4];
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
     float l[ITEMS];
@@ -371,6 +384,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_sumexp(LgDev dd) {
     TreePath path[1];
     block_upsweep_n<1>(sv, path, xch[1], tot);
     if (threadIdx.x == 0) d.bsumexp[blockIdx.x] = tot[0];
+    FBSMI_STAMP(1)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -388,6 +402,7 @@ __device__ __forceinline__ float fm_rest_at(float w, float w_k, bool is_k, int N
 template <int ITEMS, int MODE>
 __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
+    FBSMI_STAMP(2)
     __shared__ float xch[4][4];
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
     const int i_ref = d.bs[MODE == 0 ? s : d.T];
@@ -437,6 +452,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
             d.scal[2] = w_k;
         }
     }
+    FBSMI_STAMP(3)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -446,6 +462,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
 template <int ITEMS, int MODE>
 __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
+    FBSMI_STAMP(4)
     __shared__ float xch[8][4];
     __shared__ float bc[4][2];
     constexpr int TILE = kBlock * ITEMS;
@@ -559,6 +576,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
         if (base + i < d.N) d.cdfJ[base + i] = c[i];
+    FBSMI_STAMP(5)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -591,14 +609,18 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev dd, int s) {
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
     // the slot's own noise depends on nothing that is still in flight: draw it while the heap
     // gathers are outstanding
-    float xi[ITEMS][DMAX];
+    constexpr bool kHoistNoise = ITEMS * DMAX <= 16;   // more than that would spill
+    float xi[kHoistNoise ? ITEMS : 1][kHoistNoise ? DMAX : 1];
     const float u3 = uniform_at(c0, c1, 1, 0);
+    if (kHoistNoise) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i)
+        for (int i = 0; i < ITEMS; ++i)
 #pragma unroll
-        for (int r = 0; r < DMAX; ++r)
-            xi[i][r] = (r < d.du && base + i < N)
-                           ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)(base + i) * d.du + r) : 0.0f;
+            for (int r = 0; r < DMAX; ++r)
+                xi[kHoistNoise ? i : 0][kHoistNoise ? r : 0] =
+                    (r < d.du && base + i < N) ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)(base + i) * d.du + r)
+                                              : 0.0f;
+    }
     if (threadIdx.x < kHeapSize) {
         heapW[threadIdx.x] = hw;
         heapJ[threadIdx.x] = hj;
@@ -636,7 +658,9 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev dd, int s) {
             for (int r = 0; r < DMAX; ++r) {
                 if (r < d.du) {
                     const float dr = drift_row<DMAX>(t, r, u, v_prev);
-                    float x = (u[r] + dr * t.dt) + t.sd * xi[i][r];
+                    const float z = kHoistNoise ? xi[kHoistNoise ? i : 0][kHoistNoise ? r : 0]
+                                                : normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r);
+                    float x = (u[r] + dr * t.dt) + t.sd * z;
                     if (m == j_ref) x = ustar[r];
                     un[(size_t)r * N + m] = x;
                     if (d.uss) d.uss[((size_t)(s + 1) * N + m) * d.du + r] = x;
@@ -650,6 +674,150 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev dd, int s) {
     }
     mloc = block_max4(mloc, xch);
     if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
+}
+
+// ------------------------------------------------------------------------------------------
+// prop, one slot per thread, latency-optimised.  Work is indexed by the SOURCE slot p: the kill
+// test, the Cat(w) redraw, the ancestor gather, the drift and the log-weight do not depend on the
+// rotation J of the conditional killing (resamplings.py:84-85); only the destination m = p + (j*-J)
+// -- hence the noise index, the pin and the output address -- does.  So the J search and the
+// per-source chain advance together, one shared memory round trip per bisection round.
+// ------------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float xch[4];
+    __shared__ float heapW[kHeapSize], heapJ[kHeapSize];
+    FBSMI_STAMP(6)
+    const int N = d.N;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5], t0 = kt[6], t1 = kt[7];
+    const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = p < N;
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    // ---- round 0: every load whose address is known
+    const float lastJ = d.cdfJ[N - 1];
+    const float last = d.cdf[N - 1];
+    const float w_max = d.scal[1];
+    const float ws = live ? d.w[p] : 0.0f;
+    float hw = 0.0f, hj = 0.0f;
+    if (threadIdx.x >= 1 && threadIdx.x < kHeapSize) {
+        const int mid = heap_node_mid(threadIdx.x, N);
+        hw = d.cdf[mid];
+        hj = d.cdfJ[mid];
+    }
+    float uref[DMAX], usrc[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) {
+        uref[r] = r < d.du ? up[(size_t)r * N + i_ref] : 0.0f;
+        usrc[r] = (r < d.du && live) ? up[(size_t)r * N + p] : 0.0f;   // the ancestor of a survivor is itself
+    }
+    const StepTables<DMAX> t = step_tables<DMAX>(d, s);
+    const float* v_prev = d.vs + (size_t)s * d.dv;
+    const float* v = d.vs + (size_t)(s + 1) * d.dv;
+    const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
+    // uniforms that depend on nothing in flight
+    const float u3 = uniform_at(c0, c1, 1, 0);
+    const float u1 = live ? uniform_at(a0, a1, (uint64_t)N, (uint64_t)p) : 0.0f;
+    const float u2 = live ? uniform_at(b0, b1, (uint64_t)N, (uint64_t)p) : 0.0f;
+    if (threadIdx.x < kHeapSize) {
+        heapW[threadIdx.x] = hw;
+        heapJ[threadIdx.x] = hj;
+    }
+    FBSMI_STAMP(7)
+    __syncthreads();
+    FBSMI_STAMP(8)
+    const bool killed = live && (u1 * w_max >= ws);   // resamplings.py:71
+    const float qJ = lastJ * (1.0f - u3);             // :84
+    const float qK = last * (1.0f - u2);              // :73-74
+    BisectCursor cJ, cK;
+    bisect_heap_levels2(N, d.levels, heapJ, qJ, heapW, qK, cJ, cK);
+    FBSMI_STAMP(9)
+    const int Lh = d.levels < kHeapLevels ? d.levels : kHeapLevels;
+    const float* __restrict__ cdfJ = d.cdfJ;
+    const float* __restrict__ cdfW = d.cdf;
+#pragma unroll 1
+    for (int rem = d.levels - Lh; rem > 0; rem -= 3) {
+        // the 7 candidate positions of the next three levels, for both searches; issue all loads,
+        // wait once, then walk both
+        const int jl = cJ.lo, jh = cJ.hi, kl = cK.lo, kh = cK.hi;
+        const int j1 = (jl + jh) >> 1, j2l = (jl + j1) >> 1, j2r = (j1 + jh) >> 1;
+        const int j3a = (jl + j2l) >> 1, j3b = (j2l + j1) >> 1, j3c = (j1 + j2r) >> 1, j3d = (j2r + jh) >> 1;
+        const int k1 = (kl + kh) >> 1, k2l = (kl + k1) >> 1, k2r = (k1 + kh) >> 1;
+        const int k3a = (kl + k2l) >> 1, k3b = (k2l + k1) >> 1, k3c = (k1 + k2r) >> 1, k3d = (k2r + kh) >> 1;
+        const float vj1 = cdfJ[j1], vj2l = cdfJ[j2l], vj2r = cdfJ[j2r];
+        const float vj3a = cdfJ[j3a], vj3b = cdfJ[j3b], vj3c = cdfJ[j3c], vj3d = cdfJ[j3d];
+        float vk1 = 0.f, vk2l = 0.f, vk2r = 0.f, vk3a = 0.f, vk3b = 0.f, vk3c = 0.f, vk3d = 0.f;
+        if (killed) {
+            vk1 = cdfW[k1]; vk2l = cdfW[k2l]; vk2r = cdfW[k2r];
+            vk3a = cdfW[k3a]; vk3b = cdfW[k3b]; vk3c = cdfW[k3c]; vk3d = cdfW[k3d];
+        }
+        {
+            int lo = jl, hi = jh;
+            const bool g1 = qJ <= vj1;
+            hi = g1 ? j1 : hi; lo = g1 ? lo : j1;
+            const int m2 = g1 ? j2l : j2r;
+            const bool g2 = qJ <= (g1 ? vj2l : vj2r);
+            hi = g2 ? m2 : hi; lo = g2 ? lo : m2;
+            const int m3 = g1 ? (g2 ? j3a : j3b) : (g2 ? j3c : j3d);
+            const bool g3 = qJ <= (g1 ? (g2 ? vj3a : vj3b) : (g2 ? vj3c : vj3d));
+            hi = g3 ? m3 : hi; lo = g3 ? lo : m3;
+            cJ.lo = lo; cJ.hi = hi;
+        }
+        {
+            int lo = kl, hi = kh;
+            const bool g1 = qK <= vk1;
+            hi = g1 ? k1 : hi; lo = g1 ? lo : k1;
+            const int m2 = g1 ? k2l : k2r;
+            const bool g2 = qK <= (g1 ? vk2l : vk2r);
+            hi = g2 ? m2 : hi; lo = g2 ? lo : m2;
+            const int m3 = g1 ? (g2 ? k3a : k3b) : (g2 ? k3c : k3d);
+            const bool g3 = qK <= (g1 ? (g2 ? vk3a : vk3b) : (g2 ? vk3c : vk3d));
+            hi = g3 ? m3 : hi; lo = g3 ? lo : m3;
+            cK.lo = lo; cK.hi = hi;
+        }
+    }
+    FBSMI_STAMP(10)
+    const int a = killed ? cK.hi : p;
+    // ancestor gather (only killed slots need a second load)
+    float u[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) u[r] = (r < d.du && killed) ? up[(size_t)r * N + a] : usrc[r];
+    // destination slot
+    int shift = (j_ref - cJ.hi) % N;   // roll by j - J (:85)
+    if (shift < 0) shift += N;
+    int m = p + shift;
+    if (m >= N) m -= N;
+    const bool pinned = live && m == j_ref;   // idx[j] = i (:86) and us[b*] = u* (csmc.py:143)
+    if (pinned) {
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) u[r] = uref[r];
+    }
+    FBSMI_STAMP(11)
+    float mloc = -__builtin_inff();
+    if (live) {
+        if (d.As) d.As[(size_t)s * N + m] = pinned ? i_ref : a;
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) {
+            if (r < d.du) {
+                const float dr = drift_row<DMAX>(t, r, u, v_prev);
+                const float xi = normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r);
+                float x = (u[r] + dr * t.dt) + t.sd * xi;
+                if (pinned) x = ustar[r];
+                un[(size_t)r * N + m] = x;
+                if (d.uss) d.uss[((size_t)(s + 1) * N + m) * d.du + r] = x;
+            }
+        }
+        const float l = lg_loglik<DMAX>(t, u, v, v_prev);   // likelihood_logpdf on the gathered particle (csmc.py:145)
+        d.lw[m] = l;
+        mloc = l;
+    }
+    FBSMI_STAMP(12)
+    mloc = block_max4(mloc, xch);
+    if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
+    FBSMI_STAMP(13)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -755,6 +923,7 @@ struct fbsmi_lg_sweep {
     hipGraphExec_t graph_single = nullptr;  // one sweep, no chain bookkeeping
     hipGraphExec_t graph_chain = nullptr;   // one sweep + key split + advance
     bool profile = false;
+    bool legacy_prop = false;  // FBSMI_LEGACY_PROP=1: per-destination prop kernel also for one slot per thread
     int debug_mask = 15;  // FBSMI_DEBUG_STEP_MASK: bit0 norm, bit1 cdf, bit2 prop, bit3 sumexp (timing experiments only)
     std::vector<hipEvent_t> prof_ev[kNumProfKernels];  // pairs (start, stop)
     double prof_us[kNumProfKernels] = {0, 0, 0, 0};
@@ -845,7 +1014,11 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
         }
         if (s->debug_mask & 4) {
             ProfScope p(s, 2, st);
-            LG_DISPATCH(s, (k_lg_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
+            if (s->items == 1 && !s->legacy_prop) {
+                LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
+            } else {
+                LG_DISPATCH(s, (k_lg_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
+            }
         }
     }
     LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<gtile, kBlock, 0, st>>>(d)));
@@ -952,6 +1125,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     d.G = m->G; d.g = m->g; d.sd = m->sd; d.lognorm = m->lognorm; d.F = m->F; d.sqQ = m->sqQ;
     d.levels = bisect_levels(d.N);
     if (const char* dm = getenv("FBSMI_DEBUG_STEP_MASK")) s->debug_mask = atoi(dm);
+    if (const char* lp = getenv("FBSMI_LEGACY_PROP")) s->legacy_prop = atoi(lp) != 0;
     s->items = d.N <= (1 << 17) ? 1 : (d.N <= (1 << 20) ? 4 : 16);
     const int maxd = m->du > m->dv ? m->du : m->dv;
     s->dmax = maxd <= 2 ? 2 : (maxd <= 4 ? 4 : 16);
@@ -1001,6 +1175,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     rc |= dev_alloc(s, &d.acc, C * (T + 1));
     rc |= dev_alloc(s, &d.x0s_slot, 1);
     rc |= dev_alloc(s, &d.counter, 1);
+    rc |= dev_alloc(s, &d.dbg, 64);
     if (store_path) {
         rc |= dev_alloc(s, &d.As, C * T * N);
         rc |= dev_alloc(s, &d.uss, C * (T + 1) * N * d.du);
@@ -1106,6 +1281,7 @@ int fbsmi_lg_sweep_view(fbsmi_lg_sweep* s, int which, void* dst, int64_t* count,
         case 4: src = d.lwss; n = (int64_t)d.C * (d.T + 1) * d.N; break;
         case 5: src = d.us_star; n = (int64_t)d.C * (d.T + 1) * d.du; break;
         case 6: src = d.vs; n = (int64_t)d.C * (d.T + 1) * d.dv; break;
+        case 7: src = d.dbg; n = 128; break;  // 64 x uint64 as 32-bit words (diagnostic build)
         default: return fail(FBSMI_ERR_ARG, "lg_sweep_view: unknown view");
     }
     if (!src) n = 0;

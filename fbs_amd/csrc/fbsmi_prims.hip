@@ -49,6 +49,18 @@ __global__ void k_random(uint32_t k0, uint32_t k1, uint64_t n, void* out) {
     }
 }
 
+// elements [start, start+count) of the flat draw of n_total elements: what a rank that owns a
+// slice of a sharded particle ensemble needs so that its noise equals the unsharded draw
+template <int MODE>  // 0 bits, 1 uniform, 2 normal
+__global__ void k_random_range(uint32_t k0, uint32_t k1, uint64_t n_total, uint64_t start, uint64_t count, void* out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = random_bits_at(k0, k1, n_total, start + i);
+        if (MODE == 0) ((uint32_t*)out)[i] = b;
+        else if (MODE == 1) ((float*)out)[i] = fbsmi_bits_to_unit(b);
+        else ((float*)out)[i] = fbsmi_bits_to_normal(b);
+    }
+}
+
 __global__ void k_randint(uint32_t k0, uint32_t k1, uint64_t n, int32_t lo, int32_t hi, int32_t* out) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         out[i] = randint_at(k0, k1, n, i, lo, hi);
@@ -553,6 +565,19 @@ int fbsmi_normal(uint32_t k0, uint32_t k1, int64_t n, float* out, void* stream) 
     if (n < 0 || (n > 0 && !out)) return fail(FBSMI_ERR_ARG, "normal: bad arguments");
     if (n == 0) return FBSMI_OK;
     k_random<2><<<grid_for((n + 1) / 2), 256, 0, (hipStream_t)stream>>>(k0, k1, (uint64_t)n, out);
+    FBSMI_LAUNCH_CHECK();
+    return FBSMI_OK;
+}
+
+int fbsmi_random_range(int mode, uint32_t k0, uint32_t k1, int64_t n_total, int64_t start, int64_t count, void* out,
+                       void* stream) {
+    if (mode < 0 || mode > 2 || n_total < 0 || start < 0 || count < 0 || start + count > n_total || (count > 0 && !out))
+        return fail(FBSMI_ERR_ARG, "random_range: bad arguments");
+    if (count == 0) return FBSMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) k_random_range<0><<<grid_for(count), 256, 0, st>>>(k0, k1, (uint64_t)n_total, (uint64_t)start, (uint64_t)count, out);
+    else if (mode == 1) k_random_range<1><<<grid_for(count), 256, 0, st>>>(k0, k1, (uint64_t)n_total, (uint64_t)start, (uint64_t)count, out);
+    else k_random_range<2><<<grid_for(count), 256, 0, st>>>(k0, k1, (uint64_t)n_total, (uint64_t)start, (uint64_t)count, out);
     FBSMI_LAUNCH_CHECK();
     return FBSMI_OK;
 }

@@ -82,15 +82,16 @@ __device__ __forceinline__ float lg_norm_logpdf(float x, float loc, float sd2, f
     return (lognorm + (d * d) / sd2) / -2.0f;
 }
 
+// rows [row0, row0 + n) of an ensemble of n_total rows: the noise index is the global one
 __global__ void k_lg_transition_sampler(LgStep t, const float* us_prev, const float* v_prev, uint32_t k0,
-                                        uint32_t k1, int64_t n, float* us) {
+                                        uint32_t k1, int64_t n_total, int64_t row0, int64_t n, float* us) {
     const int64_t total = n * t.du;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = e / t.du;
         const int r = (int)(e - p * t.du);
         const float* u = us_prev + p * t.du;
         const float dr = lg_drift(t, r, u, v_prev);
-        const float xi = normal_at(k0, k1, (uint64_t)total, (uint64_t)e);
+        const float xi = normal_at(k0, k1, (uint64_t)(n_total * t.du), (uint64_t)(row0 * t.du + e));
         us[e] = (u[r] + dr * t.dt) + t.sd * xi;
     }
 }
@@ -177,7 +178,22 @@ int fbsmi_lg_transition_sampler(const fbsmi_lg_model* m, int32_t k, float sd_k, 
     if (rc) return rc;
     FBSMI_NEED(us_prev && v_prev && us && n >= 0, "lg_transition_sampler: bad arguments");
     if (n == 0) return FBSMI_OK;
-    k_lg_transition_sampler<<<grid_for(n * t.du), 256, 0, (hipStream_t)stream>>>(t, us_prev, v_prev, k0, k1, n, us);
+    k_lg_transition_sampler<<<grid_for(n * t.du), 256, 0, (hipStream_t)stream>>>(t, us_prev, v_prev, k0, k1, n, 0, n, us);
+    FBSMI_LAUNCH_CHECK();
+    return FBSMI_OK;
+}
+
+int fbsmi_lg_transition_sampler_rows(const fbsmi_lg_model* m, int32_t k, float sd_k, float lognorm_k,
+                                     const float* us_prev, const float* v_prev, uint32_t k0, uint32_t k1,
+                                     int64_t n_total, int64_t row0, int64_t n, float* us, void* stream) {
+    LgStep t;
+    int rc = make_step(m, k, sd_k, lognorm_k, &t);
+    if (rc) return rc;
+    FBSMI_NEED(us_prev && v_prev && us && n >= 0 && row0 >= 0 && row0 + n <= n_total,
+               "lg_transition_sampler_rows: bad arguments");
+    if (n == 0) return FBSMI_OK;
+    k_lg_transition_sampler<<<grid_for(n * t.du), 256, 0, (hipStream_t)stream>>>(t, us_prev, v_prev, k0, k1, n_total,
+                                                                                 row0, n, us);
     FBSMI_LAUNCH_CHECK();
     return FBSMI_OK;
 }

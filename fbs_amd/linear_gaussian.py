@@ -116,15 +116,23 @@ class LinearGaussianBridge:
     def _unpack(self, xy):
         return xy[..., :self.du], xy[..., self.du:]
 
-    def _transition_sampler(self, us_prev, v_prev, t_prev, key):
+    def _transition_sampler(self, us_prev, v_prev, t_prev, key, row_slice=None):
+        """row_slice = (offset, count, total): this call propagates rows [offset, offset+count) of an
+        ensemble of `total` rows (sharded ensembles); the noise is that slice of the global draw."""
         k = self.step_of(t_prev)
         up = self._t(us_prev).reshape(-1, self.du)
         vp = self._t(v_prev, (self.dv,))
         out = torch.empty_like(up)
         k0, k1 = ops._k(key)
-        _lib.call("fbsmi_lg_transition_sampler", self._ref(), k, float(self.host["sd"][k]),
-                  float(self.host["lognorm"][k]), up.data_ptr(), vp.data_ptr(), k0, k1, up.shape[0], out.data_ptr(),
-                  ops._stream())
+        if row_slice is None:
+            _lib.call("fbsmi_lg_transition_sampler", self._ref(), k, float(self.host["sd"][k]),
+                      float(self.host["lognorm"][k]), up.data_ptr(), vp.data_ptr(), k0, k1, up.shape[0],
+                      out.data_ptr(), ops._stream())
+        else:
+            offset, count, total = (int(x) for x in row_slice)
+            _lib.call("fbsmi_lg_transition_sampler_rows", self._ref(), k, float(self.host["sd"][k]),
+                      float(self.host["lognorm"][k]), up.data_ptr(), vp.data_ptr(), k0, k1, total, offset, count,
+                      out.data_ptr(), ops._stream())
         return out.reshape(us_prev.shape)
 
     def _logpdf(self, name, target, us_prev, v_prev, t_prev, dim):

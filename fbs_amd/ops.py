@@ -86,7 +86,21 @@ def random_bits(key, shape, device=None) -> torch.Tensor:
     return out.reshape(shape)
 
 
-def uniform(key, shape=(), device=None) -> torch.Tensor:
+def _draw_rows(mode, key, shape, rows, device):
+    """Rows [offset, offset+count) of the draw of `shape` (leading axis = rows): identical values to
+    slicing the full draw -- what one rank of a sharded ensemble generates."""
+    n, shape = _numel(shape)
+    offset, count = int(rows[0]), int(rows[1])
+    rowlen = n // shape[0] if shape and shape[0] else 0
+    out = torch.empty(count * rowlen, dtype=torch.float32, device=device or _default_device())
+    k0, k1 = _k(key)
+    _lib.call("fbsmi_random_range", mode, k0, k1, n, offset * rowlen, count * rowlen, out.data_ptr(), _stream())
+    return out.reshape((count,) + tuple(shape[1:]))
+
+
+def uniform(key, shape=(), device=None, rows=None) -> torch.Tensor:
+    if rows is not None:
+        return _draw_rows(1, key, shape, rows, device)
     n, shape = _numel(shape)
     out = torch.empty(n, dtype=torch.float32, device=device or _default_device())
     k0, k1 = _k(key)
@@ -94,7 +108,9 @@ def uniform(key, shape=(), device=None) -> torch.Tensor:
     return out.reshape(shape)
 
 
-def normal(key, shape=(), device=None) -> torch.Tensor:
+def normal(key, shape=(), device=None, rows=None) -> torch.Tensor:
+    if rows is not None:
+        return _draw_rows(2, key, shape, rows, device)
     n, shape = _numel(shape)
     out = torch.empty(n, dtype=torch.float32, device=device or _default_device())
     k0, k1 = _k(key)

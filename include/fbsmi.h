@@ -46,6 +46,10 @@ int fbsmi_random_bits(uint32_t k0, uint32_t k1, int64_t n, uint32_t* out, void* 
 int fbsmi_uniform(uint32_t k0, uint32_t k1, int64_t n, float* out, void* stream);
 int fbsmi_normal(uint32_t k0, uint32_t k1, int64_t n, float* out, void* stream);
 int fbsmi_randint(uint32_t k0, uint32_t k1, int64_t n, int32_t lo, int32_t hi, int32_t* out, void* stream);
+/* Elements [start, start+count) of the flat draw of n_total elements (mode 0 bits, 1 uniform,
+ * 2 normal): the slice a rank of a sharded particle ensemble owns, identical to the unsharded draw. */
+int fbsmi_random_range(int mode, uint32_t k0, uint32_t k1, int64_t n_total, int64_t start, int64_t count, void* out,
+                       void* stream);
 
 /* ---- numeric specification probes (include/fbsmi_math.h evaluated on the device) ------------
  * op: 0 exp, 1 log, 2 log1p, 3 erfinv, 4 sqrt, 5 x/y, 6 bits->normal (x reinterpreted as uint32). */
@@ -125,6 +129,11 @@ typedef struct fbsmi_lg_model {
  * transition_sampler / likelihood_logpdf / transition_logpdf of experiments/toy/gp_gibbs.py:120-135. */
 int fbsmi_lg_transition_sampler(const fbsmi_lg_model* m, int32_t k, float sd_k, float lognorm_k, const float* us_prev,
                                 const float* v_prev, uint32_t k0, uint32_t k1, int64_t n, float* us, void* stream);
+/* transition_sampler for rows [row0, row0+n) of an ensemble of n_total rows (sharded ensembles):
+ * us_prev / us hold only those n rows; the noise is the matching slice of the global draw. */
+int fbsmi_lg_transition_sampler_rows(const fbsmi_lg_model* m, int32_t k, float sd_k, float lognorm_k,
+                                     const float* us_prev, const float* v_prev, uint32_t k0, uint32_t k1,
+                                     int64_t n_total, int64_t row0, int64_t n, float* us, void* stream);
 int fbsmi_lg_likelihood_logpdf(const fbsmi_lg_model* m, int32_t k, float sd_k, float lognorm_k, const float* v,
                                const float* us_prev, const float* v_prev, int64_t n, float* lw, void* stream);
 int fbsmi_lg_transition_logpdf(const fbsmi_lg_model* m, int32_t k, float sd_k, float lognorm_k, const float* u,
@@ -156,7 +165,8 @@ int fbsmi_lg_gibbs_chain(fbsmi_lg_sweep* s, uint32_t* key, float* x0, const floa
 /* Parity views of the last sweep: copies view `which` into dst (device, nullable) and reports its
  * element count.  which: 0 final particles (n,du) row-major, 1 final normalised log-weights (n),
  * 2 As (T,n) int32, 3 uss (T+1,n,du), 4 log_wss (T+1,n) [2-4 only with store_path],
- * 5 us_star (T+1,du) and 6 vs (T+1,dv) of the sweep; each with a leading [nchains] axis.
+ * 5 us_star (T+1,du) and 6 vs (T+1,dv) of the sweep; each with a leading [nchains] axis;
+ * 7 = 128 32-bit words of in-kernel clock stamps (only written by the -DFBSMI_STAMPS diagnostic build).
  * n = nparticles (+1 if explicit_final). */
 int fbsmi_lg_sweep_view(fbsmi_lg_sweep* s, int which, void* dst, int64_t* count, void* stream);
 /* HIP-event timing hooks: average duration in microseconds of the propagate ("Euler") kernel

@@ -228,3 +228,34 @@ def test_twisted_smc_runs(oracle, dev):
                          prop_logpdf, stratified, n)
     assert xs.shape == (n, 1) and torch.isfinite(xs).all()
     assert abs(float(torch.exp(lw).sum()) - 1.0) < 1e-4
+
+
+def test_sharded_module_world1_on_gpu(oracle, dev):
+    """fbs_amd.sharded with the real (libfbsmi) backend, one rank: same answer as the oracle; and
+    the sliced PRNG draws equal slices of the full draw."""
+    from fbs_amd import sharded, ops
+    toy, ts, br = _setup(toy_4d, 15, 1.0, dev)
+    om = oracle_model_from(oracle, br)
+    N = 96
+    rng = np.random.default_rng(5)
+    x0 = rng.normal(size=br.du).astype(np.float32)
+    bs = rng.integers(0, N, 16).astype(np.int32)
+    key = oracle.PRNGKey(77)
+    sh = sharded.ParticleShards(N)
+    out = sharded.gibbs_kernel(key, torch.from_numpy(x0).to(dev), torch.from_numpy(toy["y0"]).to(dev), None, bs, ts,
+                               br.fwd_sampler, br.sde, br.unpack, N, br.transition_sampler, br.transition_logpdf,
+                               br.likelihood_logpdf, sh)
+    want = oracle.gibbs_kernel_lg(om, key, x0, toy["y0"], bs, N, True, False)
+    for a, b, w in zip(out, want, ("x0", "us_star", "bs_star", "acc")):
+        _eq(_np(a), b, w)
+    full = _np(ops.normal(key, (N, 3), device=dev))
+    part = _np(ops.normal(key, (N, 3), device=dev, rows=(32, 40)))
+    _eq(part, full[32:72], "normal rows slice")
+    fullu = _np(ops.uniform(key, (N,), device=dev))
+    _eq(_np(ops.uniform(key, (N,), device=dev, rows=(90, 6))), fullu[90:96], "uniform rows slice")
+    # a row-sliced transition equals the slice of the full transition
+    us_prev = torch.from_numpy(rng.normal(size=(N, br.du)).astype(np.float32)).to(dev)
+    v_prev = torch.from_numpy(rng.normal(size=br.dv).astype(np.float32)).to(dev)
+    whole = _np(br.transition_sampler(us_prev, v_prev, ts[3], key))
+    piece = _np(br.transition_sampler(us_prev[24:72].contiguous(), v_prev, ts[3], key, row_slice=(24, 48, N)))
+    _eq(piece, whole[24:72], "row-sliced transition")

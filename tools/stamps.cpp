@@ -1,0 +1,37 @@
+// stamps -- run sweeps on the -DFBSMI_STAMPS diagnostic build of libfbsmi and print where one
+// workgroup of each step kernel spends its time (100 MHz wall clock; shader clock for the GHz).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../include/fbsmi.h"
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 65536, T = 500, D = 2, C = argc > 2 ? atoi(argv[2]) : 1;
+    std::vector<float> G(T * D * D), g(T * D), sd(T), ln(T), F(T), sq(T);
+    for (int k = 0; k < T; ++k) { G[k*4] = -0.3f; G[k*4+1] = 0.1f; G[k*4+2] = 0.1f; G[k*4+3] = -0.4f; g[k*2] = 0.1f; g[k*2+1] = -0.1f;
+        sd[k] = 0.0632f; ln[k] = logf(6.2831853f * sd[k] * sd[k]); F[k] = 0.998f; sq[k] = 0.0632f; }
+    auto up = [](const std::vector<float>& v) { float* p; (void)hipMalloc(&p, v.size() * 4); (void)hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice); return p; };
+    fbsmi_lg_model m{1, 1, T, 2.0f / T, up(G), up(g), up(sd), up(ln), up(F), up(sq)};
+    fbsmi_lg_sweep* s = nullptr;
+    if (fbsmi_lg_sweep_create(&m, N, 1, 0, 0, C, &s)) { printf("create failed: %s\n", fbsmi_last_error()); return 1; }
+    uint32_t* key; float *x0, *y0; int32_t* bs;
+    (void)hipMalloc(&key, 8); (void)hipMalloc(&x0, 4 * C); (void)hipMalloc(&y0, 4); (void)hipMalloc(&bs, (T + 1) * 4 * C);
+    (void)hipMemset(key, 1, 8); (void)hipMemset(x0, 0, 4 * C); (void)hipMemset(y0, 0, 4); (void)hipMemset(bs, 0, (T + 1) * 4 * C);
+    hipStream_t st; (void)hipStreamCreate(&st);
+    fbsmi_lg_gibbs_chain(s, key, x0, y0, bs, 5, nullptr, 1, st); (void)hipStreamSynchronize(st);
+    unsigned long long* d; (void)hipMalloc(&d, 64 * 8); int64_t cnt = 0;
+    fbsmi_lg_sweep_view(s, 7, d, &cnt, st); (void)hipStreamSynchronize(st);
+    unsigned long long h[64]; (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    auto rt = [&](int i) { return (double)h[2 * i] * 10.0; };   // ns
+    const char* names[] = {"sumexp in", "sumexp out", "norm in", "norm out", "cdf in", "cdf out", "prop in", "prop r0 issued+ALU",
+                           "prop heap barrier", "prop LDS levels", "prop global rounds", "prop gather+dest", "prop compute+store", "prop out"};
+    // order of the last step: norm(2,3) cdf(4,5) prop(6..13) then the trailing sumexp(0,1)
+    double t0 = rt(2);
+    int order[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1};
+    double prev = t0;
+    for (int i : order) { printf("%-22s t=%8.0f ns  (+%6.0f)\n", names[i], rt(i) - t0, rt(i) - prev); prev = rt(i); }
+    double dclk = (double)(h[2 * 13 + 1] - h[2 * 6 + 1]), dns = rt(13) - rt(6);
+    printf("shader clock during prop: %.2f GHz (N=%d chains=%d)\n", dclk / dns, N, C);
+    return 0;
+}
