@@ -184,3 +184,47 @@ def make_ou_sde(a, b):
         return sim(key, x0, ts, t0=0., keep_path=keep_path)
 
     return discretise_ou_sde, cond_score_t_0, simulate_cond_forward
+
+
+def _sqrtm(mat):
+    """Symmetric PSD matrix square root by eigen-decomposition (fbs/utils.py:24-31), float64 host."""
+    vals, vecs = np.linalg.eigh(np.asarray(mat, np.float64))
+    return vecs @ np.diag(np.sqrt(vals)) @ vecs.T
+
+
+def make_gaussian_bw_sb(mean0, cov0, mean1, cov1, sig: float = 1.):
+    """Gaussian Schrodinger bridge with a Brownian reference on [0, 1] (fbs/sdes/linear.py:397-457;
+    Table 1 of "The Schrodinger Bridge between Gaussian Measures has a Closed Form", 2023).
+
+    Returns (marginal_mean(t), marginal_cov(t), drift(x, t)).  The matrices are host float64; `drift`
+    applies the affine map s(t)^T cov_t^{-1} (x - m_t) - mean0 + mean1 to a batch of states x
+    (..., d) on whatever device x lives."""
+    mean0, mean1 = np.asarray(_as_np(mean0)), np.asarray(_as_np(mean1))
+    cov0, cov1 = np.asarray(_as_np(cov0)), np.asarray(_as_np(cov1))
+    d = mean0.shape[0]
+    eye = np.eye(d)
+    sqrt0 = _sqrtm(cov0)
+    D_sig = _sqrtm(4 * sqrt0 @ cov1 @ sqrt0 + sig ** 4 * eye)
+    C_sig = 0.5 * (sqrt0 @ np.linalg.solve(sqrt0.T, D_sig.T).T - sig ** 2 * eye)
+
+    def marginal_mean(t):
+        return (1 - t) * mean0 + t * mean1
+
+    def marginal_cov(t):
+        return (1 - t) ** 2 * cov0 + t ** 2 * cov1 + t * (1 - t) * (C_sig + C_sig.T) + t * sig ** 2 * (1 - t) * eye
+
+    def s(t):
+        pt = t * cov1 + (1 - t) * C_sig
+        qt = (1 - t) * cov0 + t * C_sig
+        return pt - qt.T - sig ** 2 * t * eye
+
+    def drift(x, t):
+        t = float(t)
+        M = s(t).T @ np.linalg.inv(marginal_cov(t))          # (d, d)
+        const = mean1 - mean0 - M @ marginal_mean(t)
+        if isinstance(x, torch.Tensor):
+            Mt = torch.as_tensor(M, dtype=x.dtype, device=x.device)
+            return x @ Mt.T + torch.as_tensor(const, dtype=x.dtype, device=x.device)
+        return np.asarray(x) @ M.T + const
+
+    return marginal_mean, marginal_cov, drift
