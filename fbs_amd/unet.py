@@ -1,0 +1,413 @@
+"""The score / drift network of the image experiments as a PyTorch (ROCm) module.
+
+A restatement of the reference's flax UNet (fbs/nn/unet.py:267-368 and the blocks :42-264,
+fbs/nn/base.py:44-77, fbs/nn/utils.py:53-57) so that its matmuls / convolutions run on the MFMA
+units through PyTorch-ROCm, as BASELINE.json's north_star prescribes; nothing here is hand-written
+HIP.  Images stay channels-last at the interface ((B, H, W, C), like flax) and are viewed as NCHW
+(channels_last strides, zero copy) inside.
+
+Checkpoints of the reference are ONE flat float32 vector in ``jax.flatten_util.ravel_pytree`` order
+(fbs/nn/base.py:29-30): nested dicts flattened with keys sorted at every level, each leaf ravelled
+in C order.  ``UNet.flat_param_spec()`` reproduces that order (flax's auto-names ``Dense_0``,
+``ResnetBlock_3`` ... for unnamed sub-modules, explicit names otherwise), ``load_flat_params``
+fills the torch parameters from such a vector (flax conv kernels are (kh, kw, in, out) -> torch
+(out, in, kh, kw); Dense kernels (in, out) -> (out, in)) and ``export_flat_params`` is its inverse.
+No JAX checkpoint is available in this environment, so the ordering is PARITY UNPINNED against a
+real file; it is pinned by construction rules and round-trip tests only.
+
+Numerical conventions that differ between flax and torch defaults and are set explicitly here:
+GroupNorm eps 1e-6 (flax default), LayerNorm eps 1e-5 over the channel axis without bias,
+``nn.gelu`` = tanh approximation (flax default), weight standardisation with population variance
+and eps 1e-5, ``jax.image.resize(..., 'linear')`` = bilinear with half-pixel centres.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def sinusoidal_embedding(t: torch.Tensor, out_dim: int = 64, max_period: int = 10_000) -> torch.Tensor:
+    """fbs/nn/base.py:44-77."""
+    if out_dim % 2 == 1:
+        raise NotImplementedError(f'out_dim is implemented for even number only, while {out_dim} is given.')
+    half = out_dim // 2
+    fs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / (half - 1))
+    embs = t.unsqueeze(-1) * fs
+    return torch.cat([torch.sin(embs), torch.cos(embs)], dim=-1)
+
+
+def pixel_shuffle_nhwc(x: torch.Tensor, scale: int) -> torch.Tensor:
+    """einops 'b h w (h2 w2 c) -> b (h h2) (w w2) c' (fbs/nn/utils.py:53-57) on an NCHW tensor whose
+    channel axis is ordered (h2 w2 c)."""
+    B, Cc, H, W = x.shape
+    c = Cc // (scale * scale)
+    x = x.reshape(B, scale, scale, c, H, W)          # (b, h2, w2, c, h, w)
+    x = x.permute(0, 3, 4, 1, 5, 2)                  # (b, c, h, h2, w, w2)
+    return x.reshape(B, c, H * scale, W * scale)
+
+
+class _ChannelLayerNorm(nn.Module):
+    """flax nn.LayerNorm(epsilon=1e-5, use_bias=False) over the channel axis of an NCHW tensor."""
+
+    def __init__(self, dim: int, eps: float = 1e-5):
+        super().__init__()
+        self.scale = nn.Parameter(torch.ones(dim))
+        self.eps = eps
+
+    def forward(self, x):
+        mean = x.mean(dim=1, keepdim=True)
+        var = x.var(dim=1, unbiased=False, keepdim=True)
+        return (x - mean) * torch.rsqrt(var + self.eps) * self.scale.view(1, -1, 1, 1)
+
+
+class WeightStandardizedConv(nn.Module):
+    """fbs/nn/unet.py:77-124."""
+
+    def __init__(self, dim_in: int, features: int, kernel_size: int = 3, padding: int = 1):
+        super().__init__()
+        self.conv = nn.Conv2d(dim_in, features, kernel_size, padding=padding)
+
+    def forward(self, x):
+        w = self.conv.weight                      # (out, in, kh, kw): statistics per output channel
+        mean = w.mean(dim=(1, 2, 3), keepdim=True)
+        var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+        w = (w - mean) / torch.sqrt(var + 1e-5)
+        return F.conv2d(x, w, self.conv.bias, padding=self.conv.padding)
+
+
+class ResnetBlock(nn.Module):
+    """fbs/nn/unet.py:127-172."""
+
+    def __init__(self, dim_in: int, dim: int, time_dim: int, groups: int = 8):
+        super().__init__()
+        self.conv_0 = WeightStandardizedConv(dim_in, dim)
+        self.norm_0 = nn.GroupNorm(groups, dim, eps=1e-6)
+        self.time_mlp = nn.Linear(time_dim, 2 * dim)
+        self.conv_1 = WeightStandardizedConv(dim, dim)
+        self.norm_1 = nn.GroupNorm(groups, dim, eps=1e-6)
+        self.res_conv = nn.Conv2d(dim_in, dim, 1) if dim_in != dim else None
+
+    def forward(self, x, time_emb):
+        h = self.norm_0(self.conv_0(x))
+        te = self.time_mlp(F.silu(time_emb))[:, :, None, None]
+        scale, shift = te.chunk(2, dim=1)
+        h = F.silu(h * (1 + scale) + shift)
+        h = F.silu(self.norm_1(self.conv_1(h)))
+        if self.res_conv is not None:
+            x = self.res_conv(x)
+        return x + h
+
+
+def _l2norm(t, dim, eps=1e-12):
+    return t / torch.clamp(torch.linalg.norm(t, ord=2, dim=dim, keepdim=True), min=eps)
+
+
+class Attention(nn.Module):
+    """Full attention of the middle block, fbs/nn/unet.py:175-206."""
+
+    def __init__(self, dim: int, heads: int = 4, dim_head: int = 32, scale: int = 10):
+        super().__init__()
+        self.heads, self.dim_head, self.scale = heads, dim_head, scale
+        self.to_qkv = nn.Conv2d(dim, heads * dim_head * 3, 1, bias=False)
+        self.to_out = nn.Conv2d(heads * dim_head, dim, 1)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        q, k, v = self.to_qkv(x).chunk(3, dim=1)
+        # 'b x y (h d) -> b (x y) h d' ; the reference's l2norm uses axis=1, i.e. the (x y) axis
+        q, k, v = (t.reshape(B, self.heads, self.dim_head, H * W).permute(0, 3, 1, 2) for t in (q, k, v))
+        q, k = _l2norm(q, 1), _l2norm(k, 1)
+        sim = torch.einsum('bihd,bjhd->bhij', q, k) * self.scale
+        attn = torch.softmax(sim, dim=-1)
+        out = torch.einsum('bhij,bjhd->bhid', attn, v)                       # (b, h, xy, d)
+        out = out.permute(0, 1, 3, 2).reshape(B, self.heads * self.dim_head, H, W)   # channel = (h d)
+        return self.to_out(out)
+
+
+class LinearAttention(nn.Module):
+    """fbs/nn/unet.py:209-245."""
+
+    def __init__(self, dim: int, heads: int = 4, dim_head: int = 32):
+        super().__init__()
+        self.heads, self.dim_head = heads, dim_head
+        self.to_qkv = nn.Conv2d(dim, heads * dim_head * 3, 1, bias=False)
+        self.to_out = nn.Conv2d(heads * dim_head, dim, 1)
+        self.to_out_norm = _ChannelLayerNorm(dim)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        q, k, v = self.to_qkv(x).chunk(3, dim=1)
+        q, k, v = (t.reshape(B, self.heads, self.dim_head, H * W).permute(0, 3, 1, 2) for t in (q, k, v))  # b n h d
+        q = torch.softmax(q, dim=-1)            # over the embedding axis
+        k = torch.softmax(k, dim=-3)            # over the spatial axis
+        q = q / math.sqrt(self.dim_head)
+        v = v / (H * W)
+        context = torch.einsum('bnhd,bnhe->bhde', k, v)
+        out = torch.einsum('bhde,bnhd->bhen', context, q)                    # (b, h, e, n)
+        out = out.reshape(B, self.heads * self.dim_head, H, W)               # channel = (h e)
+        return self.to_out_norm(self.to_out(out))
+
+
+class AttnBlock(nn.Module):
+    """fbs/nn/unet.py:248-264."""
+
+    def __init__(self, dim: int, use_linear_attention: bool = True):
+        super().__init__()
+        self.norm = _ChannelLayerNorm(dim)
+        self.attn = LinearAttention(dim) if use_linear_attention else Attention(dim)
+        self.linear = use_linear_attention
+
+    def forward(self, x):
+        return self.attn(self.norm(x)) + x
+
+
+class Downsample(nn.Module):
+    def __init__(self, dim_in: int, dim: int):
+        super().__init__()
+        self.conv = nn.Conv2d(dim_in, dim, 4, stride=2, padding=1)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample(nn.Module):
+    def __init__(self, dim_in: int, dim: int, method: str = 'resize'):
+        super().__init__()
+        self.method = method
+        if method == 'resize':
+            self.convs = nn.ModuleList([nn.Conv2d(dim_in, dim, 3, padding=1)])
+        elif method == 'pixel_shuffle':
+            self.convs = nn.ModuleList([nn.Conv2d(dim_in, dim_in * 4, 3, padding=1), nn.Conv2d(dim_in, dim, 3, padding=1)])
+        else:
+            raise ValueError(f'Unknown upsampling method: {method}')
+
+    def forward(self, x):
+        if self.method == 'resize':
+            x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+            return self.convs[0](x)
+        x = pixel_shuffle_nhwc(self.convs[0](x), 2)
+        return self.convs[1](x)
+
+
+class UNet(nn.Module):
+    """fbs/nn/unet.py:267-368.  forward(x (B,H,W,C) or (H,W,C), time scalar or (B,)) -> same shape."""
+
+    def __init__(self, dt: float, dim: int, in_channels: int, upsampling: str = 'resize',
+                 init_dim: Optional[int] = None, out_dim: Optional[int] = None,
+                 dim_mults: Sequence[int] = (1, 2, 4), resnet_block_groups: int = 8, learnt_variance: bool = False):
+        super().__init__()
+        self.dt, self.dim, self.dim_mults = dt, dim, tuple(dim_mults)
+        init_dim = dim if init_dim is None else init_dim
+        self.init_dim = init_dim
+        g, td = resnet_block_groups, dim * 4
+        self.init_conv = nn.Conv2d(in_channels, init_dim, 7, padding=3)
+        self.time_dense_0 = nn.Linear(dim, td)
+        self.time_dense_1 = nn.Linear(td, td)
+        nres = len(self.dim_mults)
+        self.down_res_a, self.down_res_b = nn.ModuleList(), nn.ModuleList()
+        self.down_attn, self.down_sample = nn.ModuleList(), nn.ModuleList()
+        ch = init_dim
+        self._skip_dims: List[int] = [init_dim]
+        for ind in range(nres):
+            self.down_res_a.append(ResnetBlock(ch, ch, td, g))
+            self.down_res_b.append(ResnetBlock(ch, ch, td, g))
+            self.down_attn.append(AttnBlock(ch))
+            self._skip_dims += [ch, ch]
+            if ind < nres - 1:
+                self.down_sample.append(Downsample(ch, dim * self.dim_mults[ind]))
+                ch = dim * self.dim_mults[ind]
+        mid_dim = dim * self.dim_mults[-1]
+        self.down_last_conv = nn.Conv2d(ch, mid_dim, 3, padding=1)
+        self.mid_res_0 = ResnetBlock(mid_dim, mid_dim, td, g)
+        self.mid_attn = AttnBlock(mid_dim, use_linear_attention=False)
+        self.mid_res_1 = ResnetBlock(mid_dim, mid_dim, td, g)
+        self.up_res_0, self.up_res_1 = nn.ModuleDict(), nn.ModuleDict()
+        self.up_attn, self.up_sample = nn.ModuleDict(), nn.ModuleDict()
+        skips = list(self._skip_dims)
+        for ind in reversed(range(nres)):
+            dim_in = dim * self.dim_mults[ind]
+            dim_o = dim * self.dim_mults[ind - 1] if ind > 0 else init_dim
+            self.up_res_0[str(ind)] = ResnetBlock(dim_in + skips.pop(), dim_in, td, g)
+            self.up_res_1[str(ind)] = ResnetBlock(dim_in + skips.pop(), dim_in, td, g)
+            self.up_attn[str(ind)] = AttnBlock(dim_in)
+            if ind > 0:
+                self.up_sample[str(ind)] = Upsample(dim_in, dim_o, upsampling)
+        self.up_last_conv = nn.Conv2d(dim * self.dim_mults[0], init_dim, 3, padding=1)
+        self.final_res = ResnetBlock(init_dim + skips.pop(), dim, td, g)
+        default_out = in_channels * (2 if learnt_variance else 1)
+        self.final_conv = nn.Conv2d(dim, default_out if out_dim is None else out_dim, 1)
+
+    # ---------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, time) -> torch.Tensor:
+        squeeze = x.dim() < 4
+        if squeeze:
+            x = x.unsqueeze(0)
+        B = x.shape[0]
+        h = self.init_conv(x.permute(0, 3, 1, 2))      # NHWC -> NCHW view (channels_last strides)
+        hs = [h]
+        time = torch.as_tensor(time, dtype=torch.float32, device=x.device)
+        emb = sinusoidal_embedding(time / self.dt, out_dim=self.dim)
+        emb = emb.expand(B, self.dim) if emb.dim() < 2 else emb
+        emb = self.time_dense_1(F.gelu(self.time_dense_0(emb), approximate='tanh'))
+        nres = len(self.dim_mults)
+        for ind in range(nres):
+            h = self.down_res_a[ind](h, emb)
+            hs.append(h)
+            h = self.down_attn[ind](self.down_res_b[ind](h, emb))
+            hs.append(h)
+            if ind < nres - 1:
+                h = self.down_sample[ind](h)
+        h = self.down_last_conv(h)
+        h = self.mid_res_1(self.mid_attn(self.mid_res_0(h, emb)), emb)
+        for ind in reversed(range(nres)):
+            h = self.up_res_0[str(ind)](torch.cat([h, hs.pop()], dim=1), emb)
+            h = self.up_res_1[str(ind)](torch.cat([h, hs.pop()], dim=1), emb)
+            h = self.up_attn[str(ind)](h)
+            if ind > 0:
+                h = self.up_sample[str(ind)](h)
+        h = self.up_last_conv(h)
+        out = self.final_conv(self.final_res(torch.cat([h, hs.pop()], dim=1), emb))
+        out = out.permute(0, 2, 3, 1)
+        return out[0] if (squeeze or B == 1) else out
+
+    # ---------------------------------------------------------------------------------------------
+    # flat parameter vector in ravel_pytree order
+    # ---------------------------------------------------------------------------------------------
+    def flat_param_spec(self) -> List[Tuple[str, nn.Parameter, str]]:
+        """[(flax path, torch parameter, kind)] in ravel_pytree order.  kind: 'conv' (kh,kw,in,out),
+        'dense' (in,out), 'vec'."""
+        tree = {}
+
+        def put(path, param, kind):
+            node = tree
+            for p in path[:-1]:
+                node = node.setdefault(p, {})
+            node[path[-1]] = (param, kind)
+
+        def conv(path, m, bias=True):
+            put(path + ['kernel'], m.weight, 'conv')
+            if bias and m.bias is not None:
+                put(path + ['bias'], m.bias, 'vec')
+
+        def dense(path, m):
+            put(path + ['kernel'], m.weight, 'dense')
+            put(path + ['bias'], m.bias, 'vec')
+
+        def resblock(path, rb):
+            conv(path + ['conv_0'], rb.conv_0.conv)
+            put(path + ['norm_0', 'scale'], rb.norm_0.weight, 'vec')
+            put(path + ['norm_0', 'bias'], rb.norm_0.bias, 'vec')
+            dense(path + ['time_mlp.dense_0'], rb.time_mlp)
+            conv(path + ['conv_1'], rb.conv_1.conv)
+            put(path + ['norm_1', 'scale'], rb.norm_1.weight, 'vec')
+            put(path + ['norm_1', 'bias'], rb.norm_1.bias, 'vec')
+            if rb.res_conv is not None:
+                conv(path + ['res_conv_0'], rb.res_conv)
+
+        def attnblock(path, ab):
+            put(path + ['LayerNorm_0', 'scale'], ab.norm.scale, 'vec')
+            inner = path + ['LinearAttention_0' if ab.linear else 'Attention_0']
+            conv(inner + ['to_qkv.conv_0'], ab.attn.to_qkv, bias=False)
+            conv(inner + ['to_out.conv_0'], ab.attn.to_out)
+            if ab.linear:
+                put(inner + ['to_out.norm_0', 'scale'], ab.attn.to_out_norm.scale, 'vec')
+
+        P = ['params']
+        conv(P + ['init.conv_0'], self.init_conv)
+        dense(P + ['Dense_0'], self.time_dense_0)
+        dense(P + ['Dense_1'], self.time_dense_1)
+        nres = len(self.dim_mults)
+        for ind in range(nres):                      # unnamed ResnetBlocks are auto-numbered in call order
+            resblock(P + [f'ResnetBlock_{2 * ind}'], self.down_res_a[ind])
+            resblock(P + [f'ResnetBlock_{2 * ind + 1}'], self.down_res_b[ind])
+            attnblock(P + [f'down_{ind}.attnblock_0'], self.down_attn[ind])
+            if ind < nres - 1:
+                conv(P + [f'down_{ind}.downsample_0', 'Conv_0'], self.down_sample[ind].conv)
+        conv(P + [f'down_{nres - 1}.conv_0'], self.down_last_conv)
+        resblock(P + ['mid.resblock_0'], self.mid_res_0)
+        attnblock(P + ['mid.attenblock_0'], self.mid_attn)
+        resblock(P + ['mid.resblock_1'], self.mid_res_1)
+        for ind in range(nres):
+            resblock(P + [f'up_{ind}.resblock_0'], self.up_res_0[str(ind)])
+            resblock(P + [f'up_{ind}.resblock_1'], self.up_res_1[str(ind)])
+            attnblock(P + [f'up_{ind}.attnblock_0'], self.up_attn[str(ind)])
+            if ind > 0:
+                for j, c in enumerate(self.up_sample[str(ind)].convs):
+                    conv(P + [f'up_{ind}.upsample_0', f'Conv_{j}'], c)
+        conv(P + ['up_0.conv_0'], self.up_last_conv)
+        resblock(P + ['final.resblock_0'], self.final_res)
+        conv(P + ['final.conv_0'], self.final_conv)
+
+        out = []
+
+        def walk(node, path):
+            for key in sorted(node):                 # ravel_pytree: dict keys in sorted order
+                val = node[key]
+                if isinstance(val, dict):
+                    walk(val, path + [key])
+                else:
+                    out.append(('/'.join(path + [key]), val[0], val[1]))
+
+        walk(tree, [])
+        return out
+
+    def num_flat_params(self) -> int:
+        return sum(p.numel() for _, p, _ in self.flat_param_spec())
+
+    @torch.no_grad()
+    def load_flat_params(self, vec) -> None:
+        vec = torch.as_tensor(np.asarray(vec, np.float32) if not isinstance(vec, torch.Tensor) else vec).reshape(-1)
+        if vec.numel() != self.num_flat_params():
+            raise ValueError(f"flat parameter vector has {vec.numel()} entries, the network needs "
+                             f"{self.num_flat_params()}")
+        o = 0
+        for _, p, kind in self.flat_param_spec():
+            n = p.numel()
+            chunk = vec[o:o + n].to(p.device, p.dtype)
+            if kind == 'conv':
+                out_c, in_c, kh, kw = p.shape
+                p.copy_(chunk.reshape(kh, kw, in_c, out_c).permute(3, 2, 0, 1))
+            elif kind == 'dense':
+                out_f, in_f = p.shape
+                p.copy_(chunk.reshape(in_f, out_f).t())
+            else:
+                p.copy_(chunk.reshape(p.shape))
+            o += n
+
+    @torch.no_grad()
+    def export_flat_params(self) -> torch.Tensor:
+        parts = []
+        for _, p, kind in self.flat_param_spec():
+            if kind == 'conv':
+                parts.append(p.permute(2, 3, 1, 0).reshape(-1))
+            elif kind == 'dense':
+                parts.append(p.t().reshape(-1))
+            else:
+                parts.append(p.reshape(-1))
+        return torch.cat([q.detach().float().cpu() for q in parts])
+
+
+def make_st_nn(nn_module: UNet, param=None, device=None):
+    """fbs/nn/base.py:9-41: returns (flat parameter vector, None, forward_pass(x, t, param)).  The
+    network lives on `device`; `forward_pass` reloads the weights only when handed a different
+    vector than the one it currently holds."""
+    nn_module = nn_module.to(device) if device is not None else nn_module
+    nn_module.eval()
+    state = {"loaded": None}
+    if param is not None:
+        nn_module.load_flat_params(param)
+        state["loaded"] = id(param)
+
+    @torch.no_grad()
+    def forward_pass(x, t, p=None):
+        if p is not None and id(p) != state["loaded"]:
+            nn_module.load_flat_params(p)
+            state["loaded"] = id(p)
+        return nn_module(x, t)
+
+    return nn_module.export_flat_params(), None, forward_pass

@@ -1,0 +1,83 @@
+"""GPU: the closure tier with a (randomly initialised) UNet score on an MNIST-shaped inpainting task
+(BASELINE config 3 in miniature): gibbs_kernel / pmcmc_kernel run end to end with the mask threaded
+through **kwargs exactly as experiments/imgs/inpainting.py does, the network is evaluated once per
+step (cache), and sharded and unsharded ensembles agree."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, dim=8, T=6):
+    from fbs_amd.images import ImageRestore
+    from fbs_amd.score import ScoreBridge
+    from fbs_amd.sdes import StationaryLinLinearSDE
+    from fbs_amd.unet import UNet
+    torch.manual_seed(0)
+    Tend = 2.0
+    ts = np.linspace(0, Tend, T + 1)
+    sde = StationaryLinLinearSDE(beta_min=0.02, beta_max=5.0, t0=0.0, T=Tend)      # inpainting.py:78
+    ds = ImageRestore("inpaint-15", (28, 28, 1), device=dev)
+    net = UNet(dt=Tend / 200, dim=dim, in_channels=1, upsampling="pixel_shuffle").to(dev).eval()
+    calls = {"n": 0}
+
+    def score_fn(x, t):
+        calls["n"] += 1
+        with torch.no_grad():
+            return net(x, t).reshape(x.shape)
+
+    return ds, ScoreBridge(score_fn, ds, sde, ts, chunk=64), sde, ts, calls
+
+
+def test_gibbs_and_pmcmc_with_unet_score(oracle, dev):
+    from fbs_amd import ops
+    from fbs_amd.samplers import gibbs_kernel, pmcmc_kernel, stratified
+    ds, sb, sde, ts, calls = _setup(dev)
+    T = len(ts) - 1
+    key = oracle.PRNGKey(996)                                                   # imgs_gibbs.sh:37 seed
+    key, k_img, k_mask = oracle.split(key, 3)
+    img = ops.uniform(k_img, (28, 28, 1), device=dev)
+    mask = ds.gen_mask(k_mask)
+    x_true, y0 = ds.unpack(img, mask)
+    assert x_true.shape == (225, 1) and y0.shape == (559, 1)                    # du=225, dv=559
+    N = 24
+    x0 = torch.zeros(225, 1, device=dev)
+    bs = np.zeros(T + 1, np.int32)
+    for eb, ef in ((True, False), (True, True), (False, False)):
+        calls["n"] = 0
+        out = gibbs_kernel(key, x0, y0, None, bs, ts, sb.fwd_sampler, sde, sb.unpack, N, sb.transition_sampler,
+                           sb.transition_logpdf, sb.likelihood_logpdf, marg_y=False, explicit_backward=eb,
+                           explicit_final=ef, mask_=mask)
+        x0n, usn, bsn, acc = out
+        assert x0n.shape == (225, 1) and usn.shape == (T + 1, 225, 1) and bsn.shape == (T + 1,)
+        assert torch.isfinite(usn).all() and acc.dtype == torch.bool
+        rows = N + 1 if ef else N
+        per_step = -(-rows // 64)
+        # one network evaluation per SMC step (+1 for the explicit-final initial weights), not two
+        assert calls["n"] == per_step * (T + (1 if ef else 0)), calls["n"]
+    # pMCMC over the same closures
+    ys = sb.fwd_ys_sampler(oracle.PRNGKey(1), y0)
+    uT, ell, ys2, state = pmcmc_kernel(oracle.PRNGKey(2), x0, -1e9, ys, y0, ts, sb.fwd_ys_sampler, sde,
+                                       sb.ref_sampler, sb.transition_sampler, sb.likelihood_logpdf, stratified, N,
+                                       delta=0.005, mask_=mask)
+    assert uT.shape == (225, 1) and torch.isfinite(ell) and bool(state.is_accepted.item())
+
+
+def test_sharded_world1_equals_unsharded_with_unet(oracle, dev):
+    from fbs_amd import ops, sharded
+    from fbs_amd.samplers import gibbs_kernel
+    ds, sb, sde, ts, _ = _setup(dev)
+    T = len(ts) - 1
+    key = oracle.PRNGKey(5)
+    mask = ds.gen_mask(oracle.PRNGKey(6))
+    img = ops.uniform(oracle.PRNGKey(7), (28, 28, 1), device=dev)
+    _, y0 = ds.unpack(img, mask)
+    x0 = torch.zeros(225, 1, device=dev)
+    bs = np.arange(T + 1, dtype=np.int32) % 16
+    a = gibbs_kernel(key, x0, y0, None, bs, ts, sb.fwd_sampler, sde, sb.unpack, 16, sb.transition_sampler,
+                     sb.transition_logpdf, sb.likelihood_logpdf, mask_=mask)
+    b = sharded.gibbs_kernel(key, x0, y0, None, bs, ts, sb.fwd_sampler, sde, sb.unpack, 16, sb.transition_sampler,
+                             sb.transition_logpdf, sb.likelihood_logpdf, sharded.ParticleShards(16), mask_=mask)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

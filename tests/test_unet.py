@@ -1,0 +1,101 @@
+"""The torch restatement of the reference UNet (fbs/nn/unet.py): structure, conventions, flat-parameter
+order.  Pure torch, runs on CPU.  No JAX checkpoint exists here, so numerical parity with flax is
+unpinned; these tests pin every building block against numpy / torch references and the flat layout
+against the ravel_pytree rules."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from fbs_amd.unet import (UNet, sinusoidal_embedding, pixel_shuffle_nhwc, WeightStandardizedConv, _ChannelLayerNorm,
+                          make_st_nn)
+
+
+def test_sinusoidal_embedding_closed_form():
+    t = torch.tensor(3.7)
+    e = sinusoidal_embedding(t, out_dim=8).numpy()
+    fs = np.exp(-math.log(10000) * np.arange(4) / 3)
+    np.testing.assert_allclose(e, np.concatenate([np.sin(3.7 * fs), np.cos(3.7 * fs)]), rtol=1e-5)
+    assert sinusoidal_embedding(torch.tensor([1.0, 2.0]), out_dim=64).shape == (2, 64)
+    with pytest.raises(NotImplementedError):
+        sinusoidal_embedding(t, out_dim=7)
+
+
+def test_pixel_shuffle_matches_einops_pattern_and_torch():
+    """tests/test_nns.py:7-16 of the reference: the flax PixelShuffle equals torch's up to the channel
+    ordering convention; here additionally against the einops pattern itself."""
+    import einops
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(2, 5, 6, 12)).astype(np.float32)             # b h w (h2 w2 c), scale 2, c = 3
+    want = einops.rearrange(x, 'b h w (h2 w2 c) -> b (h h2) (w w2) c', h2=2, w2=2)
+    got = pixel_shuffle_nhwc(torch.from_numpy(x).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_array_equal(got, want)
+    # torch.nn.PixelShuffle orders channels (c h2 w2): permute channels and compare
+    xc = x.reshape(2, 5, 6, 2, 2, 3).transpose(0, 1, 2, 5, 3, 4).reshape(2, 5, 6, 12)
+    tor = torch.nn.PixelShuffle(2)(torch.from_numpy(xc).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(tor, want, atol=1e-6)
+
+
+def test_weight_standardisation_and_layernorm_conventions():
+    torch.manual_seed(0)
+    m = WeightStandardizedConv(3, 5)
+    x = torch.randn(2, 3, 8, 8)
+    w = m.conv.weight.detach().numpy()
+    ws = (w - w.mean(axis=(1, 2, 3), keepdims=True)) / np.sqrt(w.var(axis=(1, 2, 3), keepdims=True) + 1e-5)
+    want = torch.nn.functional.conv2d(x, torch.from_numpy(ws), m.conv.bias, padding=1)
+    np.testing.assert_allclose(m(x).detach().numpy(), want.detach().numpy(), atol=1e-5)
+    ln = _ChannelLayerNorm(3)
+    y = ln(x).detach().numpy()
+    xn = x.numpy()
+    ref = (xn - xn.mean(1, keepdims=True)) / np.sqrt(xn.var(1, keepdims=True) + 1e-5)
+    np.testing.assert_allclose(y, ref, atol=1e-5)
+
+
+@pytest.mark.parametrize("upsampling", ["resize", "pixel_shuffle"])
+def test_unet_shapes_and_flat_param_round_trip(upsampling):
+    torch.manual_seed(1)
+    net = UNet(dt=2.0 / 200, dim=16, in_channels=1, upsampling=upsampling, dim_mults=(1, 2, 4)).eval()
+    x = torch.randn(3, 28, 28, 1)
+    with torch.no_grad():
+        out = net(x, 0.5)
+        assert out.shape == (3, 28, 28, 1) and torch.isfinite(out).all()
+        assert net(x[0], torch.tensor(0.5)).shape == (28, 28, 1)           # unbatched call (unet.py:365-368)
+        per_t = net(x, torch.tensor([0.5, 0.5, 0.5]))
+    np.testing.assert_allclose(per_t.numpy(), out.numpy(), atol=1e-5)
+    # every torch parameter appears exactly once in the flat layout
+    spec = net.flat_param_spec()
+    assert len({id(p) for _, p, _ in spec}) == len(spec) == len(list(net.parameters()))
+    assert net.num_flat_params() == sum(p.numel() for p in net.parameters())
+    # ravel_pytree order: sorted keys at every level ('D' < 'R' < 'd' < 'f' < 'i' < 'm' < 'u'; bias < kernel < scale)
+    paths = [p for p, _, _ in spec]
+    assert paths == sorted(paths, key=lambda s: s.split('/'))
+    assert paths[0] == 'params/Dense_0/bias' and paths[1] == 'params/Dense_0/kernel'
+    assert any(p.startswith('params/ResnetBlock_5/') for p in paths)
+    assert 'params/mid.attenblock_0/Attention_0/to_qkv.conv_0/kernel' in paths
+    assert 'params/down_0.attnblock_0/LinearAttention_0/to_out.norm_0/scale' in paths
+    assert ('params/up_1.upsample_0/Conv_1/kernel' in paths) == (upsampling == 'pixel_shuffle')
+    # round trip through the flat vector, and layout of a conv kernel chunk = (kh, kw, in, out)
+    vec = net.export_flat_params()
+    net2 = UNet(dt=2.0 / 200, dim=16, in_channels=1, upsampling=upsampling, dim_mults=(1, 2, 4)).eval()
+    net2.load_flat_params(vec.numpy())
+    with torch.no_grad():
+        np.testing.assert_allclose(net2(x, 0.5).numpy(), out.numpy(), atol=1e-6)
+    assert torch.equal(net2.export_flat_params(), vec)
+    o = 0
+    for path, p, kind in spec:
+        if path == 'params/init.conv_0/kernel':
+            k = vec[o:o + p.numel()].reshape(7, 7, 1, 16)
+            assert torch.equal(k.permute(3, 2, 0, 1), p.detach())
+        o += p.numel()
+    with pytest.raises(ValueError):
+        net2.load_flat_params(np.zeros(10, np.float32))
+
+
+def test_unet_reference_configuration_size():
+    """UNet(dt=T/200, dim=64, upsampling='pixel_shuffle') of experiments/imgs/inpainting.py:85 on MNIST."""
+    net = UNet(dt=2.0 / 200, dim=64, in_channels=1, upsampling='pixel_shuffle')
+    n = net.num_flat_params()
+    assert 5_000_000 < n < 20_000_000
+    _, _, fwd = make_st_nn(net)
+    assert fwd(torch.zeros(2, 28, 28, 1), 0.3).shape == (2, 28, 28, 1)
