@@ -169,12 +169,14 @@ def main():
             import oracle as O
             h = br.host
             om = O.LGModel(br.du, br.dv, br.dt, h["G"], h["g"], h["sd"], h["lognorm"], h["F"], h["sqQ"])
+            nthreads = max(1, min(os.cpu_count() or 1, 16))
+            sweeps = max(args.cpu_sweeps, 2 if nthreads == 1 else 6)
             c0 = time.perf_counter()
-            O.bench_gibbs_lg(om, 666, np.zeros(1, np.float32), y0, N, args.cpu_sweeps)
+            _, used = O.bench_gibbs_lg(om, 666, np.zeros(1, np.float32), y0, N, sweeps, threads=nthreads)
             cdt = time.perf_counter() - c0
-            cpu = {"value": float(N) * T * args.cpu_sweeps / cdt, "unit": "particle-steps/s", "cores": 1,
-                   "kind": "port", "sample": f"{args.cpu_sweeps} sweeps of the same workload (N={N}, T={T}) on the "
-                   f"single-threaded C oracle, {cdt:.1f} s",
+            cpu = {"value": float(N) * T * sweeps / cdt, "unit": "particle-steps/s", "cores": used,
+                   "kind": "port", "sample": f"{sweeps} single-chain sweeps of the same workload (N={N}, T={T}) on the "
+                   f"C oracle with OpenMP over independent particle loops, {used} host thread(s), {cdt:.1f} s",
                    "note": "CPU restatement of the reference algorithm (not JAX: JAX is not installable here)"}
         out = {"metric": "particle-steps/sec (N x T per Gibbs sweep)", "value": value, "unit": "particle-steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -26,8 +26,10 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (see oracle/Makefile)."""
     src = os.path.join(_HERE, "fbs_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "fbsmi_math.h")
-    stale = (not os.path.exists(_SO)) or any(
-        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr))
+    so_omp = os.path.join(_HERE, "libfbs_oracle_omp.so")
+    stale = (not os.path.exists(_SO)) or (not os.path.exists(so_omp)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > min(os.path.getmtime(_SO), os.path.getmtime(so_omp))
+        for p in (src, hdr))
     if force or stale:
         if not os.path.exists(src):
             raise RuntimeError("oracle source missing and no prebuilt libfbs_oracle.so")
@@ -36,6 +38,8 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_lib_omp = None
+_SO_OMP = os.path.join(_HERE, "libfbs_oracle_omp.so")
 
 
 def lib():
@@ -45,6 +49,17 @@ def lib():
         _lib = C.CDLL(_SO)
         _declare(_lib)
     return _lib
+
+
+def lib_omp():
+    """The OpenMP build of the same source (independent particle loops on several host threads;
+    bit-identical results).  Only bench.py's cpu_baseline leg needs it."""
+    global _lib_omp
+    if _lib_omp is None:
+        build()
+        _lib_omp = C.CDLL(_SO_OMP)
+        _declare(_lib_omp)
+    return _lib_omp
 
 
 _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
@@ -110,6 +125,8 @@ def _declare(L):
     L.orc_pmcmc_filter_step_lg.argtypes = [lg, _u32p, _f32p, _f32p, C.c_int32, C.c_int, _f32p]
     L.orc_pmcmc_filter_step_lg.restype = C.c_float
     L.orc_backward_smoother_lg.argtypes = [lg, _u32p, _f32p, _f32p, C.c_int32, _f32p]
+    L.orc_num_threads.restype = C.c_int
+    L.orc_set_num_threads.argtypes = [C.c_int]
     L.orc_bench_gibbs_lg.argtypes = [lg, C.c_uint32, _f32p, _f32p, C.c_int32, C.c_int32, _f32p]
 
 
@@ -529,11 +546,17 @@ def backward_smoother_lg(m: LGModel, key, filter_us, vs):
     return traj
 
 
-def bench_gibbs_lg(m: LGModel, seed, x0, y0, nparticles, nsweeps):
+def bench_gibbs_lg(m: LGModel, seed, x0, y0, nparticles, nsweeps, threads: int = 1):
+    """nsweeps explicit-backward Gibbs sweeps (the cpu_baseline workload).  threads > 1 uses the OpenMP
+    build; returns (x0 after the sweeps, threads actually used)."""
     out = np.zeros(m.du, np.float32)
-    lib().orc_bench_gibbs_lg(m.ref, int(seed), _f32(x0).reshape(m.du), _f32(y0).reshape(m.dv), int(nparticles),
-                             int(nsweeps), out)
-    return out
+    L = lib() if threads <= 1 else lib_omp()
+    if threads > 1:
+        L.orc_set_num_threads(int(threads))
+    used = int(L.orc_num_threads()) if threads > 1 else 1
+    L.orc_bench_gibbs_lg(m.ref, int(seed), _f32(x0).reshape(m.du), _f32(y0).reshape(m.dv), int(nparticles),
+                         int(nsweeps), out)
+    return out, used
 
 
 # ------------------------------------------------------------------------------------------------

@@ -35,6 +35,32 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* Particle loops whose iterations are independent may run on several host threads (OpenMP); no
+ * reduction is parallelised, so results are bit-identical for any thread count.  This only matters
+ * for bench.py's cpu_baseline leg. */
+#ifdef _OPENMP
+#include <omp.h>
+#define ORC_PARALLEL_FOR _Pragma("omp parallel for schedule(static) if (n >= 4096)")
+#else
+#define ORC_PARALLEL_FOR
+#endif
+
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+ORC_API void orc_set_num_threads(int t) {
+#ifdef _OPENMP
+    omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* JAX PRNG (jax/_src/prng.py, threefry2x32)                             */
 /* ------------------------------------------------------------------------------------------ */
@@ -64,6 +90,7 @@ ORC_API void orc_threefry2x32(const uint32_t key[2], uint32_t c0, uint32_t c1, u
  * padded to even, first half on lane 0, second half on lane 1. */
 ORC_API void orc_random_bits(const uint32_t key[2], int64_t n, uint32_t* out) {
     const int64_t half = (n + 1) / 2;
+    ORC_PARALLEL_FOR
     for (int64_t i = 0; i < half; ++i) {
         const int64_t j = i + half;
         uint32_t o[2];
@@ -82,6 +109,7 @@ ORC_API void orc_split(const uint32_t key[2], int num, uint32_t* out) {
 ORC_API void orc_uniform(const uint32_t key[2], int64_t n, float* out) {
     uint32_t* bits = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
     orc_random_bits(key, n, bits);
+    ORC_PARALLEL_FOR
     for (int64_t i = 0; i < n; ++i) out[i] = fbsmi_bits_to_unit(bits[i]);
     free(bits);
 }
@@ -90,6 +118,7 @@ ORC_API void orc_uniform(const uint32_t key[2], int64_t n, float* out) {
 ORC_API void orc_normal(const uint32_t key[2], int64_t n, float* out) {
     uint32_t* bits = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
     orc_random_bits(key, n, bits);
+    ORC_PARALLEL_FOR
     for (int64_t i = 0; i < n; ++i) out[i] = fbsmi_bits_to_normal(bits[i]);
     free(bits);
 }
@@ -129,31 +158,43 @@ static void assoc_scan(const float* x, int64_t n, float* out) {
     const int64_t nr = n / 2;
     float* red = (float*)malloc(sizeof(float) * (size_t)nr);
     float* odd = (float*)malloc(sizeof(float) * (size_t)nr);
+    ORC_PARALLEL_FOR
     for (int64_t i = 0; i < nr; ++i) red[i] = x[2 * i] + x[2 * i + 1];
     assoc_scan(red, nr, odd);
     out[0] = x[0];
+    ORC_PARALLEL_FOR
     for (int64_t i = 0; i < nr; ++i) out[2 * i + 1] = odd[i];
-    for (int64_t i = 0; 2 * i + 2 < n; ++i) out[2 * i + 2] = odd[i] + x[2 * i + 2];
+    const int64_t ne = (n - 1) / 2; /* number of i with 2i + 2 < n */
+    ORC_PARALLEL_FOR
+    for (int64_t i = 0; i < ne; ++i) out[2 * i + 2] = odd[i] + x[2 * i + 2];
     free(red);
     free(odd);
 }
 
 ORC_API void orc_cumsum(const float* x, int64_t n, float* out) { assoc_scan(x, n, out); }
 
-static float tree_sum_rec(const float* x, int64_t lo, int64_t size, int64_t n) {
-    if (lo >= n) return 0.0f;
-    if (size == 1) return x[lo];
-    const int64_t h = size / 2;
-    if (lo + h >= n) return tree_sum_rec(x, lo, h, n);
-    return tree_sum_rec(x, lo, h, n) + tree_sum_rec(x, lo + h, h, n);
-}
-
-/* sum = root of the pairwise tree over x zero-padded to a power of two (x + 0 == x). */
+/* sum = root of the pairwise tree over x zero-padded to a power of two (x + 0 == x): level by level,
+ * node i of the next level = node 2i + node 2i+1 (a missing right node contributes nothing). */
 ORC_API float orc_sum(const float* x, int64_t n) {
     if (n <= 0) return 0.0f;
-    int64_t p = 1;
-    while (p < n) p <<= 1;
-    return tree_sum_rec(x, 0, p, n);
+    float* a = (float*)malloc(sizeof(float) * (size_t)n);
+    float* b = (float*)malloc(sizeof(float) * (size_t)n);
+    memcpy(a, x, sizeof(float) * (size_t)n);
+    int64_t m = n;
+    while (m > 1) {
+        const int64_t h = m / 2;
+        ORC_PARALLEL_FOR
+        for (int64_t i = 0; i < h; ++i) b[i] = a[2 * i] + a[2 * i + 1];
+        if (m & 1) b[h] = a[m - 1];
+        m = h + (m & 1);
+        float* t = a;
+        a = b;
+        b = t;
+    }
+    const float r = a[0];
+    free(a);
+    free(b);
+    return r;
 }
 
 ORC_API float orc_max(const float* x, int64_t n) {
@@ -181,6 +222,7 @@ ORC_API void orc_choice(const uint32_t key[2], const float* w, int32_t n, int64_
     float* u = (float*)malloc(sizeof(float) * (size_t)(m > 0 ? m : 1));
     orc_cumsum(w, n, c);
     orc_uniform(key, m, u);
+    ORC_PARALLEL_FOR
     for (int64_t i = 0; i < m; ++i) out[i] = orc_searchsorted(c, n, c[n - 1] * (1.0f - u[i]));
     free(c);
     free(u);
@@ -191,6 +233,7 @@ ORC_API float orc_logsumexp(const float* x, int64_t n) {
     float m = orc_max(x, n);
     if (!(fabsf(m) <= 3.40282347e+38f)) m = 0.0f;
     float* e = (float*)malloc(sizeof(float) * (size_t)n);
+    ORC_PARALLEL_FOR
     for (int64_t i = 0; i < n; ++i) e[i] = fbsmi_expf(x[i] - m);
     const float s = orc_sum(e, n);
     free(e);
@@ -200,6 +243,7 @@ ORC_API float orc_logsumexp(const float* x, int64_t n) {
 /* csmc.normalise (fbs/samplers/csmc/csmc.py:273-292) */
 ORC_API void orc_normalise(float* lw, int64_t n, int log_space) {
     const float c = orc_logsumexp(lw, n);
+    ORC_PARALLEL_FOR
     for (int64_t i = 0; i < n; ++i) {
         lw[i] = lw[i] - c;
         if (!log_space) lw[i] = fbsmi_expf(lw[i]);
@@ -207,6 +251,7 @@ ORC_API void orc_normalise(float* lw, int64_t n, int log_space) {
 }
 
 ORC_API void orc_exp(const float* x, int64_t n, float* out) {
+    ORC_PARALLEL_FOR
     for (int64_t i = 0; i < n; ++i) out[i] = fbsmi_expf(x[i]);
 }
 ORC_API void orc_log(const float* x, int64_t n, float* out) {
@@ -303,6 +348,7 @@ static void killing_core(const uint32_t key[2], const float* w, int32_t n, int32
     int32_t* ch = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
     orc_uniform(keys3, n, u);
     orc_choice(keys3 + 2, w, n, n, ch);
+    ORC_PARALLEL_FOR
     for (int32_t i = 0; i < n; ++i) {
         const int killed = u[i] * w_max >= w[i];
         idx[i] = killed ? ch[i] : i;
@@ -338,6 +384,7 @@ ORC_API void orc_cond_killing(const uint32_t key[2], const float* w, int32_t i, 
     killing_core(key, w, n, idx, k3, &w_max);
     if (!conditional) return;
     float* jp = (float*)malloc(sizeof(float) * (size_t)n);
+    ORC_PARALLEL_FOR
     for (int32_t m = 0; m < n; ++m) jp[m] = (1.0f - w[m] / w_max) / (float)n;   /* :79 */
     jp[i] = 0.0f;                                                                /* :80 */
     float jpi = 1.0f - orc_sum(jp, n);                                           /* :81 */
@@ -350,6 +397,7 @@ ORC_API void orc_cond_killing(const uint32_t key[2], const float* w, int32_t i, 
     memcpy(tmp, idx, sizeof(int32_t) * (size_t)n);
     long long s = ((long long)j - J) % n;
     if (s < 0) s += n;
+    ORC_PARALLEL_FOR
     for (int32_t m = 0; m < n; ++m) idx[(m + s) % n] = tmp[m];
     idx[j] = i;                                                                  /* :86 */
     free(tmp);
@@ -453,6 +501,7 @@ ORC_API void orc_lg_transition_sampler(const orc_lg* m, int k, const float* us_p
     const int du = m->du;
     float* xi = (float*)malloc(sizeof(float) * (size_t)n * du);
     orc_normal(key, (int64_t)n * du, xi);
+    ORC_PARALLEL_FOR
     for (int32_t p = 0; p < n; ++p) {
         const float* u = us_prev + (size_t)p * du;
         for (int r = 0; r < du; ++r) {
@@ -468,6 +517,7 @@ ORC_API void orc_lg_likelihood_logpdf(const orc_lg* m, int k, const float* v, co
                                       const float* v_prev, int32_t n, float* lw) {
     const int du = m->du, dv = m->dv;
     const float sd2 = m->sd[k] * m->sd[k];
+    ORC_PARALLEL_FOR
     for (int32_t p = 0; p < n; ++p) {
         const float* u = us_prev + (size_t)p * du;
         float acc = 0.0f;
@@ -553,6 +603,7 @@ ORC_API void orc_csmc_forward_pass_lg(const orc_lg* m, const uint32_t key[2], co
         orc_exp(lw, n, w);
         if (resampler == 0) orc_cond_killing(kk, w, bs_star[k], bs_star[k + 1], 1, n, A);
         else orc_cond_multinomial(kk, w, bs_star[k], bs_star[k + 1], 1, n, A);
+        ORC_PARALLEL_FOR
         for (int32_t p = 0; p < n; ++p)                                        /* jnp.take :140 */
             memcpy(us_prev + (size_t)p * du, us + (size_t)A[p] * du, sizeof(float) * (size_t)du);
         orc_lg_transition_sampler(m, k, us_prev, v_prev, kk + 2, n, us);       /* :142 */

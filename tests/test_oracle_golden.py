@@ -263,3 +263,13 @@ def test_backward_passes_return_consistent_trajectories(oracle):
     xs2, Bs2 = oracle.backward_sampling_pass_lg(m, key, vs, fp["uss"], fp["log_wss"])
     for k in range(31):
         np.testing.assert_array_equal(xs2[k], fp["uss"][k, Bs2[k]])
+
+
+def test_openmp_build_is_bit_identical(oracle):
+    """The OpenMP variant (cpu_baseline leg of bench.py) parallelises only independent particle
+    loops: same bits as the serial build at any thread count."""
+    m, toy = _toy_model(oracle, 20, 1.0)
+    a, _ = oracle.bench_gibbs_lg(m, 7, [0.0], toy["y0"], 8192, 1, threads=1)
+    b, used = oracle.bench_gibbs_lg(m, 7, [0.0], toy["y0"], 8192, 1, threads=4)
+    assert used >= 1
+    assert a.view(np.uint32) == b.view(np.uint32)
