@@ -86,6 +86,9 @@ SIGNATURES = {
     "fbsmi_lg_gibbs_sweep": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "fbsmi_lg_gibbs_chain": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_int, _vp]),
     "fbsmi_lg_sweep_view": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(_i64), _vp]),
+    "fbsmi_lg_filter_create": (C.c_int, [C.POINTER(LGModelStruct), _i32, C.c_int, C.c_int, C.c_int, _i32, C.POINTER(_vp)]),
+    "fbsmi_lg_filter_destroy": (None, [_vp]),
+    "fbsmi_lg_filter_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "fbsmi_lg_sweep_profile": (C.c_int, [_vp, C.c_int]),
     "fbsmi_lg_sweep_kernel_us": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
 }

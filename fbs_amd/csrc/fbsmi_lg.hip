@@ -84,6 +84,11 @@ struct LgDev {
     float** x0s_slot;  // device slot holding the x0s pointer (or null)
     int32_t* counter;  // device sweep counter
     unsigned long long* dbg;  // [64] in-kernel stamps (diagnostic build -DFBSMI_STAMPS only)
+    // fused particle filters (bootstrap_filter / pmcmc_filter_step)
+    int flow;        // 0 bootstrap_filter (smc.py:58-74), 1 pmcmc_filter_step (smc.py:138-152)
+    int systematic;  // resampling: 0 stratified, 1 systematic (resampling.py:43-59)
+    float logn;      // log(nparticles)
+    float* ell;      // [C] running log-likelihood (flow 1) / negative log-likelihood (flow 0)
 };
 
 #ifdef FBSMI_STAMPS
@@ -130,6 +135,7 @@ __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
     d.usn += (T + 1) * du * c;
     d.bsn += (T + 1) * c;
     d.acc += (T + 1) * c;
+    if (d.ell) d.ell += c;
     return d;
 }
 
@@ -821,6 +827,197 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused particle filters for the analytic model: bootstrap_filter (fbs/samplers/smc.py:9-88) and
+// pmcmc_filter_step (smc.py:115-158) with stratified / systematic resampling
+// (fbs/samplers/resampling.py:43-59).  Same four dependency levels per step as the Gibbs sweep:
+//   sumexp -> fnorm (lse, w, log-likelihood accumulator, partials of w) -> cdf -> fprop.
+// The two functions order a step differently:
+//   bootstrap : propagate(us_prev) ; weight(us_prev) ; resample the NEW particles
+//               => fprop(k) = [resample with step k-1's weights] gather, propagate, weight (old)
+//   pmcmc     : weight(us) ; resample ; propagate
+//               => fprop(k) = resample, gather, propagate, weight the NEW particle for step k+1
+// ------------------------------------------------------------------------------------------
+// keys: bootstrap: key -> (key_init, key_steps); keys = split(key_steps, T)        smc.py:77-79
+//       pmcmc    : keys = split(key, T)                                            smc.py:154
+//       step     : keys[k] -> (key_proposal, key_resampling)                       smc.py:61,142
+__global__ void __launch_bounds__(kBlock) k_filt_keys(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    uint32_t s0 = d.keys[0], s1 = d.keys[1];
+    if (d.flow == 0) split_at(d.keys[0], d.keys[1], 2, 1, s0, s1);
+    for (int k = threadIdx.x; k < d.T; k += kBlock) {
+        uint32_t q0, q1;
+        split_at(s0, s1, d.T, k, q0, q1);
+        uint32_t* kt = d.keytab + 8 * k;
+        split_at(q0, q1, 2, 0, kt[0], kt[1]);  // key_proposal
+        split_at(q0, q1, 2, 1, kt[2], kt[3]);  // key_resampling
+    }
+    if (threadIdx.x == 0) *d.ell = 0.0f;
+}
+
+// u0s (n, du) row-major -> u0 (SoA); pmcmc: log-weights of step 0 on the initial particles
+template <int ITEMS, int DMAX>
+__global__ void __launch_bounds__(kBlock) k_filt_init(LgDev dd, const float* u0s_all) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float xch[4];
+    const float* u0s = u0s_all + (size_t)blockIdx.y * d.N * d.du;
+    const StepTables<DMAX> t = step_tables<DMAX>(d, 0);
+    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    float mloc = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int p = base + i;
+        if (p < d.N) {
+            float u[DMAX];
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) {
+                u[r] = r < d.du ? u0s[(size_t)p * d.du + r] : 0.0f;
+                if (r < d.du) {
+                    d.u0[(size_t)r * d.N + p] = u[r];
+                    if (d.uss) d.uss[(size_t)p * d.du + r] = u[r];
+                }
+            }
+            if (d.flow == 1) {
+                const float l = lg_loglik<DMAX>(t, u, d.vs + d.dv, d.vs);   // smc.py:144, k = 0
+                d.lw[p] = l;
+                mloc = fmaxf(mloc, l);
+            }
+        }
+    }
+    if (d.flow == 1) {
+        mloc = block_max4(mloc, xch);
+        if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
+    }
+}
+
+// fnorm: c = logsumexp(lw); accumulate the (negative) log-likelihood; w = exp(lw - c); partials
+template <int ITEMS>
+__global__ void __launch_bounds__(kBlock) k_filt_norm(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float xch[3][4];
+    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    float l[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) l[i] = base + i < d.N ? d.lw[base + i] : 0.0f;
+    float bs4[kTopItems];
+    top_load(d.bsumexp, d.nb, bs4);
+    float mloc = wave_max(top_load_max(d.bmax, d.nb));
+    if ((threadIdx.x & 63) == 0) xch[0][threadIdx.x >> 6] = mloc;
+    float sv[1] = {chunk_total<kTopItems>(bs4)}, tot[1];
+    TreePath tp[1];
+    block_upsweep_n<1>(sv, tp, xch[1], tot);
+    const float Mraw = fmaxf(fmaxf(xch[0][0], xch[0][1]), fmaxf(xch[0][2], xch[0][3]));
+    const float c = fbsmi_logf(tot[0]) + finite_or_zero(Mraw);
+    float xw[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int e = base + i;
+        xw[i] = 0.0f;
+        if (e < d.N) {
+            const float w = fbsmi_expf(l[i] - c);   // smc.py:68-69 / :147-148
+            d.w[e] = w;
+            xw[i] = w;
+        }
+    }
+    float s1[1] = {chunk_total<ITEMS>(xw)}, t1[1];
+    TreePath p1[1];
+    block_upsweep_n<1>(s1, p1, xch[2], t1);
+    if (threadIdx.x == 0) {
+        d.bsumw[blockIdx.x] = t1[0];
+        if (blockIdx.x == 0) {
+            const float e0 = *d.ell;
+            *d.ell = d.flow == 0 ? e0 - (c - d.logn)      // log_nell -= _c - log(N)          smc.py:67
+                                 : (e0 - d.logn) + c;      // log_ell = log_ell - log(N) + _c  smc.py:146
+        }
+    }
+}
+
+// fprop.  RESAMPLE: draw ancestors from the current cdf with resample key of step `kres`.
+// WEIGHT: 0 none, 1 weight the gathered (old) particle with step s tables, 2 weight the new
+// particle with step s+1 tables.  PROPAGATE: false = gather only (the final resampling of
+// bootstrap_filter).
+template <int ITEMS, int DMAX>
+__global__ void __launch_bounds__(kBlock) k_filt_prop(LgDev dd, int s, int resample, int kres, int weight,
+                                                      int propagate) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float xch[4];
+    __shared__ float heapW[kHeapSize];
+    const int N = d.N;
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    float last = 0.0f;
+    if (resample) {
+        last = d.cdf[N - 1];
+        if (threadIdx.x >= 1 && threadIdx.x < kHeapSize) heapW[threadIdx.x] = d.cdf[heap_node_mid(threadIdx.x, N)];
+    }
+    (void)last;
+    const uint32_t* ktp = d.keytab + 8 * (s < d.T ? s : d.T - 1);
+    const uint32_t p0 = ktp[0], p1 = ktp[1];
+    const uint32_t r0 = d.keytab[8 * kres + 2], r1 = d.keytab[8 * kres + 3];
+    const float u_sys = (resample && d.systematic) ? uniform_at(r0, r1, 1, 0) : 0.0f;
+    __syncthreads();
+    const int st = s < d.T ? s : d.T - 1;
+    const StepTables<DMAX> t = step_tables<DMAX>(d, st);
+    const StepTables<DMAX> tn = step_tables<DMAX>(d, st + 1 < d.T ? st + 1 : st);
+    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    float mloc = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int m = base + i;
+        if (m < N) {
+            int a = m;
+            if (resample) {   // _systematic_or_stratified, resampling.py:43-51
+                const float uu = d.systematic ? u_sys : uniform_at(r0, r1, (uint64_t)N, (uint64_t)m);
+                const float q = ((float)m + uu) / (float)N;
+                a = bisect_heap(d.cdf, N, d.levels, heapW, q);
+                a = a < 0 ? 0 : (a > N - 1 ? N - 1 : a);
+            }
+            float u[DMAX];
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) u[r] = r < d.du ? up[(size_t)r * N + a] : 0.0f;
+            if (!propagate) {   // final resampling of bootstrap_filter: us[inds]  (smc.py:72)
+#pragma unroll
+                for (int r = 0; r < DMAX; ++r)
+                    if (r < d.du) {
+                        d.usT[(size_t)m * d.du + r] = u[r];
+                        if (d.uss) d.uss[((size_t)d.T * N + m) * d.du + r] = u[r];
+                    }
+                continue;
+            }
+            if (d.uss && d.flow == 0 && s > 0) {   // filtering_samples[s] = resampled particles of step s-1
+#pragma unroll
+                for (int r = 0; r < DMAX; ++r)
+                    if (r < d.du) d.uss[((size_t)s * N + m) * d.du + r] = u[r];
+            }
+            float x[DMAX];
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) {
+                x[r] = 0.0f;
+                if (r < d.du) {
+                    const float dr = drift_row<DMAX>(t, r, u, d.vs + (size_t)s * d.dv);
+                    const float z = normal_at(p0, p1, (uint64_t)N * d.du, (uint64_t)m * d.du + r);
+                    x[r] = (u[r] + dr * t.dt) + t.sd * z;                 // transition_sampler
+                    un[(size_t)r * N + m] = x[r];
+                    if (s == d.T - 1 && d.flow == 1) d.usT[(size_t)m * d.du + r] = x[r];
+                }
+            }
+            if (weight == 1) {         // measurement_cond_pdf(v, us_prev, v_prev, t_prev)      smc.py:65
+                const float l = lg_loglik<DMAX>(t, u, d.vs + (size_t)(s + 1) * d.dv, d.vs + (size_t)s * d.dv);
+                d.lw[m] = l;
+                mloc = fmaxf(mloc, l);
+            } else if (weight == 2) {  // next step's likelihood_logpdf on the propagated particle  smc.py:144
+                const float l = lg_loglik<DMAX>(tn, x, d.vs + (size_t)(s + 2) * d.dv, d.vs + (size_t)(s + 1) * d.dv);
+                d.lw[m] = l;
+                mloc = fmaxf(mloc, l);
+            }
+        }
+    }
+    if (weight) {
+        mloc = block_max4(mloc, xch);
+        if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // sweep epilogue
 // ------------------------------------------------------------------------------------------
 // explicit backward (gibbs.py:152-154): force_move tail, x0 = uss[-1, idx]
@@ -1291,6 +1488,112 @@ int fbsmi_lg_sweep_view(fbsmi_lg_sweep* s, int which, void* dst, int64_t* count,
         FBSMI_HIP_TRY(hipStreamSynchronize(s->stream));
         FBSMI_HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * esz, hipMemcpyDeviceToDevice, ust));
     }
+    return FBSMI_OK;
+}
+
+// ---- fused particle filters ------------------------------------------------------------------
+struct fbsmi_lg_filter {
+    fbsmi_lg_sweep* core = nullptr;  // buffers, stream, events
+    float* u0s = nullptr;            // [C][n][du] staging of the initial particles
+    hipGraphExec_t graph = nullptr;
+};
+
+namespace {
+
+int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
+    fbsmi_lg_sweep* s = f->core;
+    const LgDev& d = s->d;
+    const dim3 gone(1, d.C), gtile(d.nb, d.C);
+    k_filt_keys<<<gone, kBlock, 0, st>>>(d);
+    LG_DISPATCH(s, (k_filt_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, f->u0s)));
+    for (int k = 0; k < d.T; ++k) {
+        if (d.flow == 0)
+            LG_DISPATCH(s, (k_filt_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k, k > 0, k > 0 ? k - 1 : 0, 1, 1)));
+        LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<gtile, kBlock, 0, st>>>(d)));
+        LG_DISPATCH(s, (void)DMAX; (k_filt_norm<ITEMS><<<gtile, kBlock, 0, st>>>(d)));
+        LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 2><<<gtile, kBlock, 0, st>>>(d, d.T)));
+        if (d.flow == 1)
+            LG_DISPATCH(s, (k_filt_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k, 1, k, k + 1 < d.T ? 2 : 0, 1)));
+    }
+    if (d.flow == 0)
+        LG_DISPATCH(s, (k_filt_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, d.T, 1, d.T - 1, 0, 0)));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("filter launch: ") + hipGetErrorString(e));
+    return FBSMI_OK;
+}
+
+}  // namespace
+
+int fbsmi_lg_filter_create(const fbsmi_lg_model* m, int32_t nparticles, int flow, int resampling, int store_path,
+                           int32_t nchains, fbsmi_lg_filter** out) {
+    if (!out || flow < 0 || flow > 1 || resampling < 0 || resampling > 1)
+        return fail(FBSMI_ERR_ARG, "lg_filter_create: flow must be 0|1 and resampling 0 (stratified) | 1 (systematic)");
+    if (flow == 1 && store_path) return fail(FBSMI_ERR_ARG, "lg_filter_create: pmcmc_filter_step keeps no path");
+    fbsmi_lg_sweep* core = nullptr;
+    int rc = fbsmi_lg_sweep_create(m, nparticles, 1, 0, store_path, nchains, &core);
+    if (rc) return rc;
+    fbsmi_lg_filter* f = new (std::nothrow) fbsmi_lg_filter();
+    if (!f) {
+        fbsmi_lg_sweep_destroy(core);
+        return fail(FBSMI_ERR_ARG, "out of host memory");
+    }
+    f->core = core;
+    LgDev& d = core->d;
+    d.flow = flow;
+    d.systematic = resampling;
+    d.logn = (float)log((double)nparticles);
+    if (dev_alloc(core, &d.ell, (size_t)d.C) || dev_alloc(core, &f->u0s, (size_t)d.C * d.N * d.du)) {
+        fbsmi_lg_sweep_destroy(core);
+        delete f;
+        return FBSMI_ERR_HIP;
+    }
+    *out = f;
+    return FBSMI_OK;
+}
+
+void fbsmi_lg_filter_destroy(fbsmi_lg_filter* f) {
+    if (!f) return;
+    if (f->core && f->core->stream) hipStreamSynchronize(f->core->stream);
+    if (f->graph) hipGraphExecDestroy(f->graph);
+    fbsmi_lg_sweep_destroy(f->core);
+    delete f;
+}
+
+int fbsmi_lg_filter_run(fbsmi_lg_filter* f, const uint32_t* keys, const float* vs, const float* u0s, float* uT,
+                        float* loglik, float* path, int use_graph, void* stream) {
+    if (!f || !keys || !vs || !u0s) return fail(FBSMI_ERR_ARG, "lg_filter_run: null input");
+    fbsmi_lg_sweep* s = f->core;
+    const LgDev& d = s->d;
+    if (path && !d.uss) return fail(FBSMI_ERR_ARG, "lg_filter_run: path requested but the filter was created without store_path");
+    hipStream_t ust = (hipStream_t)stream;
+    const size_t C = d.C, T1 = d.T + 1;
+    FBSMI_HIP_TRY(hipEventRecord(s->ev_in, ust));
+    FBSMI_HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_in, 0));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.keys, keys, C * 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(d.vs, vs, C * T1 * d.dv * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipMemcpyAsync(f->u0s, u0s, C * d.N * d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    if (use_graph) {
+        if (!f->graph) {
+            hipGraph_t g = nullptr;
+            FBSMI_HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+            int rc = enqueue_filter(f, s->stream);
+            hipError_t e = hipStreamEndCapture(s->stream, &g);
+            if (rc) return rc;
+            if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            FBSMI_HIP_TRY(hipGraphInstantiate(&f->graph, g, nullptr, nullptr, 0));
+            FBSMI_HIP_TRY(hipGraphDestroy(g));
+        }
+        FBSMI_HIP_TRY(hipGraphLaunch(f->graph, s->stream));
+    } else {
+        int rc = enqueue_filter(f, s->stream);
+        if (rc) return rc;
+    }
+    if (uT) FBSMI_HIP_TRY(hipMemcpyAsync(uT, d.usT, C * d.N * d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    if (loglik) FBSMI_HIP_TRY(hipMemcpyAsync(loglik, d.ell, C * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    if (path)
+        FBSMI_HIP_TRY(hipMemcpyAsync(path, d.uss, C * T1 * d.N * d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    FBSMI_HIP_TRY(hipEventRecord(s->ev_out, s->stream));
+    FBSMI_HIP_TRY(hipStreamWaitEvent(ust, s->ev_out, 0));
     return FBSMI_OK;
 }
 

@@ -195,6 +195,14 @@ class LinearGaussianBridge:
             self._sweeps[keyt] = h
         return h
 
+    def filter_handle(self, nparticles: int, flow: str, resampling: str = "stratified", store_path: bool = False):
+        keyt = ("filter", int(nparticles), flow, resampling, bool(store_path))
+        h = self._sweeps.get(keyt)
+        if h is None:
+            h = LGFilter(self, int(nparticles), flow, resampling, bool(store_path))
+            self._sweeps[keyt] = h
+        return h
+
     def gibbs_kernel(self, key, x0, y0, bs_star, nparticles, explicit_backward=True, explicit_final=False,
                      use_graph=True):
         """One fused sweep; same returns as fbs.samplers.gibbs_kernel: (x0, us_star, bs_star, acc)."""
@@ -299,3 +307,41 @@ class LGSweep:
         n = C.c_int64()
         _lib.call("fbsmi_lg_sweep_kernel_us", self.h, int(which), C.byref(avg), C.byref(n))
         return avg.value, n.value
+
+
+class LGFilter:
+    """Fused bootstrap_filter (flow='bootstrap', smc.py:9-88) / pmcmc_filter_step (flow='pmcmc',
+    smc.py:115-158) for the analytic model: one hipGraph replay per call."""
+
+    _FLOW = {"bootstrap": 0, "pmcmc": 1}
+    _RES = {"stratified": 0, "systematic": 1}
+
+    def __init__(self, model: LinearGaussianBridge, nparticles, flow, resampling, store_path):
+        self.model, self.n, self.flow, self.store = model, nparticles, flow, store_path
+        h = C.c_void_p()
+        with torch.cuda.device(model.device):
+            _lib.call("fbsmi_lg_filter_create", C.byref(model.struct), nparticles, self._FLOW[flow],
+                      self._RES[resampling], int(store_path), 1, C.byref(h))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.lib().fbsmi_lg_filter_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def run(self, key, vs, u0s, use_graph=True):
+        """-> (particles (n, du), log-likelihood scalar tensor[, filtering path (T+1, n, du)])."""
+        m = self.model
+        k = np.asarray(key.detach().cpu() if isinstance(key, torch.Tensor) else key).astype(np.uint32).reshape(1, 2)
+        kt = torch.from_numpy(k.view(np.int32).copy()).to(m.device)
+        vst = m._t(vs).reshape(m.T + 1, m.dv)
+        u0t = m._t(u0s).reshape(self.n, m.du)
+        uT = torch.empty((self.n, m.du), dtype=torch.float32, device=m.device)
+        ell = torch.empty(1, dtype=torch.float32, device=m.device)
+        path = torch.empty((m.T + 1, self.n, m.du), dtype=torch.float32, device=m.device) if self.store else None
+        _lib.call("fbsmi_lg_filter_run", self.h, kt.data_ptr(), vst.data_ptr(), u0t.data_ptr(), uT.data_ptr(),
+                  ell.data_ptr(), path.data_ptr() if path is not None else None, int(bool(use_graph)), ops._stream())
+        return (uT, ell.reshape(())) if path is None else (uT, ell.reshape(()), path)

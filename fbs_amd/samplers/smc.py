@@ -12,13 +12,34 @@ import numpy as np
 import torch
 
 from .. import ops
+from . import resampling as _resampling
 from .common import MCMCState
+
+
+def _fused_filter(transition_sampler, weight_closure, resampling, kwargs):
+    """(model, resampling name) when the fused analytic-model filter applies, else None."""
+    model = getattr(transition_sampler, "_fbsmi_lg", None)
+    if model is None or getattr(weight_closure, "_fbsmi_lg", None) is not model or kwargs:
+        return None
+    if getattr(weight_closure, "_role", "") != "likelihood_logpdf" or max(model.du, model.dv) > 16:
+        return None
+    name = "stratified" if resampling is _resampling.stratified else (
+        "systematic" if resampling is _resampling.systematic else None)
+    return (model, name) if name else None
 
 
 def bootstrap_filter(transition_sampler, measurement_cond_pdf, vs, ts, init_sampler, key, nparticles, resampling,
                      log: bool = True, return_last: bool = True, **kwargs):
     """Bootstrap particle filter (smc.py:9-88) -> (samples, negative log-likelihood)."""
     nsteps = vs.shape[0] - 1
+    fused = _fused_filter(transition_sampler, measurement_cond_pdf, resampling, kwargs) if log else None
+    if fused is not None and fused[0].T == nsteps:
+        model, rname = fused
+        key_init, _ = ops.split(key, 2)                                             # :77
+        init_samples = init_sampler(key_init, vs[0], nparticles)                    # :78
+        out = model.filter_handle(nparticles, "bootstrap", rname, store_path=not return_last).run(key, vs, init_samples)
+        return (out[0].reshape(init_samples.shape), out[1]) if return_last else (
+            out[2].reshape((nsteps + 1,) + tuple(init_samples.shape)), out[1])
     key_init, key_steps = ops.split(key, 2)                                         # :77
     us_prev = init_sampler(key_init, vs[0], nparticles)                             # :78
     keys = ops.split(key_steps, nsteps)                                             # :79
@@ -63,6 +84,11 @@ def pmcmc_filter_step(key, vs_bridge, u0s, ts, transition_sampler, likelihood_lo
                       **kwargs):
     """Particle filter inside pMCMC (smc.py:115-158): weight -> resample old -> propagate."""
     nsteps = (ts.shape[0] if hasattr(ts, "shape") else len(ts)) - 1
+    fused = _fused_filter(transition_sampler, likelihood_logpdf, resampling, kwargs)
+    if fused is not None and fused[0].T == nsteps:
+        model, rname = fused
+        uT, ell = model.filter_handle(nparticles, "pmcmc", rname).run(key, vs_bridge, u0s)
+        return uT.reshape(u0s.shape), ell
     keys = ops.split(key, nsteps)                                                   # :154
     us = u0s
     log_ell = torch.zeros((), dtype=torch.float32, device=u0s.device)

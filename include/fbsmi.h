@@ -169,6 +169,20 @@ int fbsmi_lg_gibbs_chain(fbsmi_lg_sweep* s, uint32_t* key, float* x0, const floa
  * 7 = 128 32-bit words of in-kernel clock stamps (only written by the -DFBSMI_STAMPS diagnostic build).
  * n = nparticles (+1 if explicit_final). */
 int fbsmi_lg_sweep_view(fbsmi_lg_sweep* s, int which, void* dst, int64_t* count, void* stream);
+/* Fused particle filters for the analytic model, stratified (resampling = 0) or systematic (1)
+ * resampling (fbs/samplers/resampling.py:43-59):
+ *   flow 0  bootstrap_filter (fbs/samplers/smc.py:9-88); loglik receives the NEGATIVE log-likelihood
+ *           estimate; with store_path the filtering path (T+1, n, du) can be fetched (return_last=False);
+ *   flow 1  pmcmc_filter_step (smc.py:115-158); loglik receives log_ell.
+ * keys (C,2), vs (C,T+1,dv) the reversed observation path, u0s (C,n,du) row-major initial particles
+ * are device inputs; uT (C,n,du), loglik (C), path (C,T+1,n,du) device outputs (nullable). */
+typedef struct fbsmi_lg_filter fbsmi_lg_filter;
+int fbsmi_lg_filter_create(const fbsmi_lg_model* model, int32_t nparticles, int flow, int resampling, int store_path,
+                           int32_t nchains, fbsmi_lg_filter** out);
+void fbsmi_lg_filter_destroy(fbsmi_lg_filter* f);
+int fbsmi_lg_filter_run(fbsmi_lg_filter* f, const uint32_t* keys, const float* vs, const float* u0s, float* uT,
+                        float* loglik, float* path, int use_graph, void* stream);
+
 /* HIP-event timing hooks: average duration in microseconds of the propagate ("Euler") kernel
  * over the launches since the last reset; 0 launches -> returns 0. Only measured when
  * fbsmi_lg_sweep_profile(s, 1) was set (events force non-graph launches). */

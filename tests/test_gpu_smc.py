@@ -259,3 +259,38 @@ def test_sharded_module_world1_on_gpu(oracle, dev):
     whole = _np(br.transition_sampler(us_prev, v_prev, ts[3], key))
     piece = _np(br.transition_sampler(us_prev[24:72].contiguous(), v_prev, ts[3], key, row_slice=(24, 48, N)))
     _eq(piece, whole[24:72], "row-sliced transition")
+
+
+@pytest.mark.parametrize("resampling", ["stratified", "systematic"])
+@pytest.mark.parametrize("toy,n,T", [(toy_2d, 128, 30), (toy_4d, 1000, 12), (toy_2d, 70000, 6)])
+def test_fused_filters_match_oracle(toy, n, T, resampling, oracle, dev):
+    """The fused (hipGraph) bootstrap_filter / pmcmc_filter_step of the analytic model, reached through
+    the unchanged fbs_amd.samplers.smc signatures, against the oracle -- and against the closure tier."""
+    from fbs_amd.samplers import smc
+    from fbs_amd.samplers import resampling as R
+    toy, ts, br = _setup(toy, T, 2.0, dev)
+    om = oracle_model_from(oracle, br)
+    k1, k2, k3 = oracle.split(oracle.PRNGKey(41), 3)
+    vs = oracle.lg_fwd_sampler(om, k1, toy["y0"])[::-1].copy()
+    init = oracle.normal(k2, (n, br.du))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    res = getattr(R, resampling)
+    init_sampler = lambda k, v0, m_: t(init)
+    filt, nell = smc.bootstrap_filter(br.transition_sampler, br.likelihood_logpdf, t(vs), ts, init_sampler, k3, n, res,
+                                      log=True, return_last=False)
+    wfilt, wnell = oracle.bootstrap_filter_lg(om, k3, vs, init, resampling, return_last=False)
+    _eq(_np(filt), wfilt, "fused filtering path")
+    _eq(np.float32(nell.item()), np.float32(wnell), "fused nell")
+    last, nell2 = smc.bootstrap_filter(br.transition_sampler, br.likelihood_logpdf, t(vs), ts, init_sampler, k3, n, res)
+    _eq(_np(last), wfilt[-1], "fused last")
+    _eq(np.float32(nell2.item()), np.float32(wnell), "fused nell (return_last)")
+    uT, ell = smc.pmcmc_filter_step(k3, t(vs), t(init), ts, br.transition_sampler, br.likelihood_logpdf, res, n)
+    wuT, well = oracle.pmcmc_filter_step_lg(om, k3, vs, init, resampling)
+    _eq(_np(uT), wuT, "fused pmcmc uT")
+    _eq(np.float32(ell.item()), np.float32(well), "fused log_ell")
+    # the closure tier (plain lambdas hide the descriptor) gives the same bits
+    if n <= 1000:
+        uT2, ell2 = smc.pmcmc_filter_step(k3, t(vs), t(init), ts, lambda *a: br.transition_sampler(*a),
+                                          lambda *a: br.likelihood_logpdf(*a), res, n)
+        _eq(_np(uT2), wuT, "closure-tier pmcmc uT")
+        _eq(np.float32(ell2.item()), np.float32(well), "closure-tier log_ell")
