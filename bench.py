@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sweeps", type=int, default=2)
     ap.add_argument("--no-single-chain", action="store_true")
+    ap.add_argument("--batch-scan", type=str, default="16,32",
+                    help="extra chain-batch sizes timed (untimed region) and reported in `batch_scan`; '' to skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -164,6 +166,21 @@ def main():
             sdt = (time.perf_counter() - s0) / nrep
             single = {"value": float(N) * T / sdt, "unit": "particle-steps/s", "ms_per_sweep": sdt * 1e3,
                       "note": "same workload with nchains=1 on this GPU (latency-bound: one chain cannot fill the chip)"}
+        scan = None
+        if world == 1 and args.batch_scan and not args.no_single_chain:
+            scan = []
+            for cb in [int(x) for x in args.batch_scan.split(",") if x]:
+                swb = br.sweep_handle(N, True, False, nchains=cb)
+                kb, xb, bb, _ = swb.chain(key, np.zeros((cb, 1), np.float32), y0, np.zeros((cb, T + 1), np.int32), 1,
+                                          keep=False)
+                torch.cuda.synchronize(dev)
+                b0 = time.perf_counter()
+                swb.chain(kb, xb, y0, bb, 3, keep=False)
+                torch.cuda.synchronize(dev)
+                bdt = (time.perf_counter() - b0) / 3
+                scan.append({"nchains": cb, "value": float(N) * T * cb / bdt, "ms_per_sweep": bdt * 1e3,
+                             "whole_sweep_GBps": bpp["step"] * float(N) * T * cb / bdt / 1e9})
+                del swb
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             import oracle as O
@@ -188,7 +205,7 @@ def main():
                           "(reference driver default nchains=4, vmapped)",
                           "nparticles": N, "nsteps": T, "nchains": C, "du": br.du, "dv": br.dv,
                           "parallelism": f"{world} GPU(s) x {C} independent chain(s) each, no collective"},
-               "roofline": roofline, "cpu_baseline": cpu, "single_chain": single,
+               "roofline": roofline, "cpu_baseline": cpu, "single_chain": single, "batch_scan": scan,
                "x0_mean_of_timed_sweeps": float(x0s.float().mean().item())}
     if dist is not None:
         dist.barrier()

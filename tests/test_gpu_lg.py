@@ -242,3 +242,23 @@ def test_baseline_config2_one_sweep(oracle, dev):
     assert abs(w.sum() - 1) < 1e-4
     b = _np(got[2])
     assert b.min() >= 0 and b.max() < N
+
+
+def test_toy_driver_targets_the_gp_posterior(tmp_path, dev):
+    """examples/toy_gibbs.py (counterpart of experiments/toy/gp_gibbs.py, d = 10, joint dimension 20,
+    4 vmapped chains, explicit backward): the chains must recover the GP-regression posterior, the
+    closed form the reference's tabulators compare against (tabulate_toy.py:46-52)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "toy_gibbs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "toy_gibbs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    samples, gp_mean, gp_cov = mod.main(["--d", "10", "--nparticles", "100", "--nsamples", "1500", "--explicit_backward",
+                                         "--nchains", "4", "--outdir", str(tmp_path), "--quiet"])
+    assert samples.shape == (4, 1500, 10)
+    x = samples[:, 200:].reshape(-1, 10).astype(np.float64)
+    assert np.abs(x.mean(0) - gp_mean).max() < 0.12
+    assert np.abs(np.diag(np.cov(x.T)) - np.diag(gp_cov)).max() < 0.1
+    saved = np.load(os.path.join(str(tmp_path), "gibbs-eb-const-100-666.npz"))
+    assert set(saved.files) == {"samples", "gp_mean", "gp_cov"}
