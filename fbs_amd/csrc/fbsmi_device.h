@@ -431,6 +431,65 @@ __device__ __forceinline__ void top_leaf(const float (&x)[kTopItems], const Tree
 }
 
 // ------------------------------------------------------------------------------------------
+// Two-level logsumexp (specified in include/fbsmi_math.h): a workgroup tile publishes
+// (m_t = max, s_t = tree-sum exp(x - m_t')), consumers combine the per-tile pairs.  One grid-wide
+// dependency instead of the two of "global max, then sum".
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float finite_or_zero_f(float m) { return (fabsf(m) <= 3.40282347e+38f) ? m : 0.0f; }
+
+// producer: l[] = this thread's log-weights (-inf where there is no element).  lds_a, lds_b: 4
+// floats each, untouched since the last barrier.
+template <int ITEMS>
+__device__ __forceinline__ void block_lse_partial(const float (&l)[ITEMS], float* lds_a, float* lds_b, float& m_out,
+                                                  float& s_out) {
+    float m = l[0];
+#pragma unroll
+    for (int i = 1; i < ITEMS; ++i) m = fmaxf(m, l[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) lds_a[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(lds_a[0], lds_a[1]), fmaxf(lds_a[2], lds_a[3]));
+    const float mp = finite_or_zero_f(m);
+    float x[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) x[i] = fbsmi_expf(l[i] - mp);
+    float sv[1] = {chunk_total<ITEMS>(x)}, tot[1];
+    TreePath path[1];
+    block_upsweep_n<1>(sv, path, lds_b, tot);
+    m_out = m;
+    s_out = tot[0];
+}
+
+// consumer (up to kMaxTopBlock tiles): lse and the raw global max
+__device__ __forceinline__ void lse_from_partials(const float* __restrict__ pmax, const float* __restrict__ psum, int nb,
+                                                  float* lds_a, float* lds_b, float& lse, float& Mraw) {
+    float m4[kTopItems], s4[kTopItems];
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < kTopItems; ++i) {
+        const int e = threadIdx.x * kTopItems + i;
+        m4[i] = e < nb ? pmax[e] : -__builtin_inff();
+        s4[i] = e < nb ? psum[e] : 0.0f;
+        m = fmaxf(m, m4[i]);
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) lds_a[threadIdx.x >> 6] = m;
+    __syncthreads();
+    Mraw = fmaxf(fmaxf(lds_a[0], lds_a[1]), fmaxf(lds_a[2], lds_a[3]));
+    const float Mp = finite_or_zero_f(Mraw);
+    float t4[kTopItems];
+#pragma unroll
+    for (int i = 0; i < kTopItems; ++i) {
+        const int e = threadIdx.x * kTopItems + i;
+        t4[i] = e < nb ? s4[i] * fbsmi_expf(finite_or_zero_f(m4[i]) - Mp) : 0.0f;
+    }
+    float sv[1] = {chunk_total<kTopItems>(t4)}, tot[1];
+    TreePath path[1];
+    block_upsweep_n<1>(sv, path, lds_b, tot);
+    lse = fbsmi_logf(tot[0]) + Mp;
+}
+
+// ------------------------------------------------------------------------------------------
 // Fast exact bisection.  The first Lh <= 8 levels of the fixed bisection visit a fixed implicit
 // tree of at most 255 array positions: a workgroup gathers them into LDS once (one memory round
 // trip), and every search walks them there.  The remaining levels go three at a time: the 7
@@ -451,10 +510,6 @@ __device__ __forceinline__ int heap_node_mid(int t, int n) {
     }
     return (lo + hi) >> 1;
 }
-
-struct BisectState {
-    int lo, hi;
-};
 
 __device__ __forceinline__ int bisect_heap(const float* __restrict__ a, int n, int levels, const float* heap,
                                            float q) {
@@ -487,20 +542,12 @@ __device__ __forceinline__ int bisect_heap(const float* __restrict__ a, int n, i
     return hi;
 }
 
-// The same bisection as a resumable cursor, so that two independent searches can share their
-// memory round trips (issue both probe sets, wait once, apply both).
-struct BisectCursor {
-    int lo, hi;
-};
-
-struct BisectProbe {
-    int m1, m2l, m2r, m3a, m3b, m3c, m3d;
-    float v1, v2l, v2r, v3a, v3b, v3c, v3d;
-};
-
-__device__ __forceinline__ BisectCursor bisect_heap_levels(int n, int levels, const float* heap, float q) {
-    int lo = 0, hi = n, t = 1;
-    const int Lh = levels < kHeapLevels ? levels : kHeapLevels;
+// Building blocks of the one-slot-per-thread kernels.
+// The LDS part of the walk over a heap of Lh levels (node 0 unused):
+__device__ __forceinline__ void bisect_lds_levels(int n, int Lh, const float* heap, float q, int& lo, int& hi) {
+    lo = 0;
+    hi = n;
+    int t = 1;
     for (int l = 0; l < Lh; ++l) {
         const int mid = (lo + hi) >> 1;
         const bool gl = q <= heap[t];
@@ -508,63 +555,56 @@ __device__ __forceinline__ BisectCursor bisect_heap_levels(int n, int levels, co
         lo = gl ? lo : mid;
         t = 2 * t + (gl ? 0 : 1);
     }
-    return BisectCursor{lo, hi};
 }
 
-// two searches walking the LDS levels in lockstep (their LDS reads overlap)
-__device__ __forceinline__ void bisect_heap_levels2(int n, int levels, const float* heapA, float qA,
-                                                    const float* heapB, float qB, BisectCursor& cA,
-                                                    BisectCursor& cB) {
-    int loA = 0, hiA = n, tA = 1, loB = 0, hiB = n, tB = 1;
-    const int Lh = levels < kHeapLevels ? levels : kHeapLevels;
-    for (int l = 0; l < Lh; ++l) {
-        const float hA = heapA[tA], hB = heapB[tB];
-        const int midA = (loA + hiA) >> 1, midB = (loB + hiB) >> 1;
-        const bool gA = qA <= hA, gB = qB <= hB;
-        hiA = gA ? midA : hiA;
-        loA = gA ? loA : midA;
-        tA = 2 * tA + (gA ? 0 : 1);
-        hiB = gB ? midB : hiB;
-        loB = gB ? loB : midB;
-        tB = 2 * tB + (gB ? 0 : 1);
+// Three levels in one memory round trip (`on` = false: no loads, interval untouched)
+__device__ __forceinline__ void bisect_round3(const float* __restrict__ a, int& lo, int& hi, float q, bool on) {
+    if (!on) return;
+    const int l0 = lo, h0 = hi;
+    const int m1 = (l0 + h0) >> 1;
+    const int m2l = (l0 + m1) >> 1, m2r = (m1 + h0) >> 1;
+    const int m3a = (l0 + m2l) >> 1, m3b = (m2l + m1) >> 1, m3c = (m1 + m2r) >> 1, m3d = (m2r + h0) >> 1;
+    const float v1 = a[m1], v2l = a[m2l], v2r = a[m2r], v3a = a[m3a], v3b = a[m3b], v3c = a[m3c], v3d = a[m3d];
+    int l = l0, h = h0;
+    const bool g1 = q <= v1;
+    h = g1 ? m1 : h;
+    l = g1 ? l : m1;
+    const int m2 = g1 ? m2l : m2r;
+    const bool g2 = q <= (g1 ? v2l : v2r);
+    h = g2 ? m2 : h;
+    l = g2 ? l : m2;
+    const int m3 = g1 ? (g2 ? m3a : m3b) : (g2 ? m3c : m3d);
+    const bool g3 = q <= (g1 ? (g2 ? v3a : v3b) : (g2 ? v3c : v3d));
+    h = g3 ? m3 : h;
+    l = g3 ? l : m3;
+    lo = l;
+    hi = h;
+}
+
+// A search whose query is the same for the whole workgroup (the rotation J): after the LDS levels
+// the interval [lo, hi) is workgroup-uniform; once it is at most kBlock wide the workgroup fetches
+// it whole in ONE round trip and every thread finishes the walk in LDS.  win: kBlock floats.
+__device__ __forceinline__ int bisect_uniform(const float* __restrict__ a, int n, int levels, int Lh, const float* heap,
+                                              float* win, float q) {
+    int lo, hi;
+    bisect_lds_levels(n, Lh, heap, q, lo, hi);
+    int rem = levels - Lh;
+    while (rem > 0 && hi - lo > kBlock) {
+        bisect_round3(a, lo, hi, q, true);
+        rem -= 3;
     }
-    cA = BisectCursor{loA, hiA};
-    cB = BisectCursor{loB, hiB};
-}
-
-__device__ __forceinline__ void bisect_issue(const float* __restrict__ a, const BisectCursor& c, BisectProbe& p) {
-    const int lo = c.lo, hi = c.hi;
-    p.m1 = (lo + hi) >> 1;
-    p.m2l = (lo + p.m1) >> 1;
-    p.m2r = (p.m1 + hi) >> 1;
-    p.m3a = (lo + p.m2l) >> 1;
-    p.m3b = (p.m2l + p.m1) >> 1;
-    p.m3c = (p.m1 + p.m2r) >> 1;
-    p.m3d = (p.m2r + hi) >> 1;
-    p.v1 = a[p.m1];
-    p.v2l = a[p.m2l];
-    p.v2r = a[p.m2r];
-    p.v3a = a[p.m3a];
-    p.v3b = a[p.m3b];
-    p.v3c = a[p.m3c];
-    p.v3d = a[p.m3d];
-}
-
-__device__ __forceinline__ void bisect_apply(BisectCursor& c, const BisectProbe& p, float q) {
-    int lo = c.lo, hi = c.hi;
-    const bool g1 = q <= p.v1;
-    hi = g1 ? p.m1 : hi;
-    lo = g1 ? lo : p.m1;
-    const int m2 = g1 ? p.m2l : p.m2r;
-    const bool g2 = q <= (g1 ? p.v2l : p.v2r);
-    hi = g2 ? m2 : hi;
-    lo = g2 ? lo : m2;
-    const int m3 = g1 ? (g2 ? p.m3a : p.m3b) : (g2 ? p.m3c : p.m3d);
-    const bool g3 = q <= (g1 ? (g2 ? p.v3a : p.v3b) : (g2 ? p.v3c : p.v3d));
-    hi = g3 ? m3 : hi;
-    lo = g3 ? lo : m3;
-    c.lo = lo;
-    c.hi = hi;
+    if (rem > 0) {   // uniform branch: q, lo, hi and rem are the same in every thread
+        const int w0 = lo, e = lo + (int)threadIdx.x;
+        win[threadIdx.x] = a[e < n ? e : n - 1];
+        __syncthreads();
+        for (int l = 0; l < rem; ++l) {
+            const int mid = (lo + hi) >> 1;
+            const bool gl = q <= win[mid - w0];
+            hi = gl ? mid : hi;
+            lo = gl ? lo : mid;
+        }
+    }
+    return hi;
 }
 
 // logsumexp's "amax if finite else 0" (jax.scipy.special.logsumexp)

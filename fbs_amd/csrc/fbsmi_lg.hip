@@ -4,21 +4,21 @@
 // sampler (fbs/sdes/linear.py:190-221) and the three model closures of
 // experiments/toy/gp_gibbs.py:120-135 folded in, entirely on the device.
 //
-// One SMC step has four grid-wide dependency levels, each a kernel (kernel boundaries are the
+// One SMC step has three grid-wide dependency levels, each a kernel (kernel boundaries are the
 // cheapest grid-wide synchronisation on MI355X, ~1.5 us):
 //
-//   norm  : lse from the previous kernel's per-workgroup partials; w = exp(lw - lse);
+//   norm  : lse from the (max, sumexp) pairs the previous kernel published per workgroup (two-level
+//           logsumexp, include/fbsmi_math.h); w = exp(lw - lse);
 //           w_max = exp(max lw - lse) (fbsmi_expf is monotone, so this IS max_i w_i);
 //           per-workgroup tree sums of w and of J_prob                        [csmc.py:146,139]
 //   cdf   : canonical-tree cumsum of w and of J_prob (J_prob[i*] needs the total first)
 //                                                                        [resamplings.py:74-84]
 //   prop  : J ~ Cat(J_prob); per slot: rotate by j*-J, kill test, Cat(w) draw for killed slots,
 //           pin, gather the ancestor, Euler-Maruyama step, pin the reference, Gaussian
-//           log-weight, per-workgroup max                      [resamplings.py:71-86, csmc.py:140-145]
-//   sumexp: per-workgroup tree sums of exp(lw - max)                          [csmc.py:289]
+//           log-weight, per-workgroup (max, sumexp)                      [resamplings.py:71-86, csmc.py:140-145]
 //
 // Particle state is structure-of-arrays u[r][p] so that every per-slot access is coalesced.
-// A whole sweep (4T + ~10 launches) is captured once into a hipGraph and replayed.
+// A whole sweep (3T + ~10 launches) is captured once into a hipGraph and replayed.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -34,7 +34,7 @@
 namespace fbsmi {
 
 constexpr int kMaxNbSweep = 1024;  // workgroup partials one in-kernel top tree handles
-constexpr int kNumProfKernels = 4; // norm, cdf, prop, sumexp
+constexpr int kNumProfKernels = 3; // norm, cdf, prop
 
 struct LgDev {
     int C;           // independent chains batched in every launch (blockIdx.y): jax.vmap over chains
@@ -70,6 +70,8 @@ struct LgDev {
     float* cdf;        // [N]
     float* cdfJ;       // [N]
     float *bmax, *bsumexp, *bsumw, *bsumJ;  // [nb]
+    float *hpW, *hpJ;                       // compact bisection heaps of cdf / cdfJ (one slot per thread only)
+    int lh_w, lh_j;                         // their depths
     float* scal;       // [16]: 0 lse, 1 w_max
     int32_t* As;       // [T][N] or null
     float* uss;        // [T+1][N][du] or null
@@ -104,6 +106,10 @@ struct LgDev {
 
 // The view of chain c: every per-chain array advanced to that chain's slice (all per-chain arrays
 // are laid out [C][...]).
+// depths of the compact heaps the cdf kernel publishes for k_lg_prop1
+constexpr int kHeapLevelsW = 11, kHeapSizeW = 1 << kHeapLevelsW;
+constexpr int kHeapLevelsJ = 8, kHeapSizeJ = 1 << kHeapLevelsJ;
+
 __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
     const size_t N = d.N, T = d.T, D = d.D, du = d.du, dv = d.dv, nb = d.nb;
     d.keys += 2 * (size_t)c;
@@ -126,6 +132,10 @@ __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
     d.bsumexp += nb * c;
     d.bsumw += nb * c;
     d.bsumJ += nb * c;
+    if (d.hpW) {
+        d.hpW += (size_t)kHeapSizeW * c;
+        d.hpJ += (size_t)kHeapSizeJ * c;
+    }
     d.scal += 16 * (size_t)c;
     if (d.As) d.As += T * N * c;
     if (d.uss) d.uss += (T + 1) * N * du * c;
@@ -325,14 +335,15 @@ __device__ __forceinline__ float lg_loglik(const StepTables<DMAX>& t, const floa
 template <int ITEMS, int DMAX>
 __global__ void __launch_bounds__(kBlock) k_lg_init(LgDev dd) {
     const LgDev d = chain_view(dd, blockIdx.y);
-    __shared__ float s4[4];
+    __shared__ float xch[2][4];
     const StepTables<DMAX> t = step_tables<DMAX>(d, 0);
     const int b0 = d.bs[0];
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
-    float mloc = -__builtin_inff();
+    float lv[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int p = base + i;
+        lv[i] = -__builtin_inff();
         if (p < d.N) {
             float u[DMAX];
 #pragma unroll
@@ -351,15 +362,19 @@ __global__ void __launch_bounds__(kBlock) k_lg_init(LgDev dd) {
             // gibbs.py:136-137: likelihood_logpdf(vs[0], u0s, vs[1], ts[0]) ; :143-144: -log(nparticles)
             const float l = d.ef ? lg_loglik<DMAX>(t, u, d.vs, d.vs + d.dv) : d.lw_init;
             d.lw[p] = l;
-            mloc = fmaxf(mloc, l);
+            lv[i] = l;
         }
     }
-    mloc = block_max(mloc, s4);
-    if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
+    float m, sx;
+    block_lse_partial<ITEMS>(lv, xch[0], xch[1], m, sx);
+    if (threadIdx.x == 0) {
+        d.bmax[blockIdx.x] = m;
+        d.bsumexp[blockIdx.x] = sx;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-// The four step kernels.  Each is latency-bound (a few hundred bytes per workgroup), so they are
+// The three step kernels.  Each is latency-bound (a few hundred bytes per workgroup), so they are
 // written to keep the dependent chain short: every global load whose address is known is issued
 // at entry, reductions that are independent share one LDS exchange (block_upsweep_n), the
 // per-workgroup partials of the previous kernel are re-reduced through a tile-shaped top tree
@@ -370,27 +385,6 @@ __device__ __forceinline__ float block_max4(float m, float* lds4) {  // lds4 unt
     if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = m;
     __syncthreads();
     return fmaxf(fmaxf(lds4[0], lds4[1]), fmaxf(lds4[2], lds4[3]));
-}
-
-// sumexp: per-workgroup tree sums of exp(lw - amax)   (logsumexp, csmc.py:289)
-template <int ITEMS>
-__global__ void __launch_bounds__(kBlock) k_lg_sumexp(LgDev dd) {
-    const LgDev d = chain_view(dd, blockIdx.y);
-    FBSMI_STAMP(0)
-    __shared__ float xch[2][4];
-    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
-    float l[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) l[i] = base + i < d.N ? d.lw[base + i] : 0.0f;
-    const float M = finite_or_zero(block_max4(top_load_max(d.bmax, d.nb), xch[0]));
-    float x[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) x[i] = base + i < d.N ? fbsmi_expf(l[i] - M) : 0.0f;
-    float sv[1] = {chunk_total<ITEMS>(x)}, tot[1];
-    TreePath path[1];
-    block_upsweep_n<1>(sv, path, xch[1], tot);
-    if (threadIdx.x == 0) d.bsumexp[blockIdx.x] = tot[0];
-    FBSMI_STAMP(1)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -408,7 +402,7 @@ __device__ __forceinline__ float fm_rest_at(float w, float w_k, bool is_k, int N
 template <int ITEMS, int MODE>
 __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
-    FBSMI_STAMP(2)
+    if (MODE == 0) { FBSMI_STAMP(2) }
     __shared__ float xch[4][4];
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
     const int i_ref = d.bs[MODE == 0 ? s : d.T];
@@ -416,17 +410,10 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) l[i] = base + i < d.N ? d.lw[base + i] : 0.0f;
     const float l_ref = MODE == 1 ? d.lw[i_ref] : 0.0f;
-    float bs4[kTopItems];
-    top_load(d.bsumexp, d.nb, bs4);
-    float mloc = top_load_max(d.bmax, d.nb);
-    // max of the maxima and root of the sumexp partials: one exchange
-    float sv[1] = {chunk_total<kTopItems>(bs4)}, tot[1];
-    TreePath tp[1];
-    mloc = wave_max(mloc);
-    if ((threadIdx.x & 63) == 0) xch[0][threadIdx.x >> 6] = mloc;
-    block_upsweep_n<1>(sv, tp, xch[1], tot);
-    const float Mraw = fmaxf(fmaxf(xch[0][0], xch[0][1]), fmaxf(xch[0][2], xch[0][3]));
-    const float lse = fbsmi_logf(tot[0]) + finite_or_zero(Mraw);
+    // two-level logsumexp: combine the per-workgroup (max, sumexp) pairs the previous kernel published
+    float lse, Mraw;
+    lse_from_partials(d.bmax, d.bsumexp, d.nb, xch[0], xch[1], lse, Mraw);
+    if (MODE == 0) { FBSMI_STAMP(14) }
     const float w_max = fbsmi_expf(Mraw - lse);  // == max_i w_i: fbsmi_expf is monotone
     const float w_k = MODE == 1 ? fbsmi_expf(l_ref - lse) : 0.0f;
     float xw[ITEMS], xj[ITEMS];
@@ -458,7 +445,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
             d.scal[2] = w_k;
         }
     }
-    FBSMI_STAMP(3)
+    if (MODE == 0) { FBSMI_STAMP(3) }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -468,7 +455,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
 template <int ITEMS, int MODE>
 __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
-    FBSMI_STAMP(4)
+    if (MODE == 0) { FBSMI_STAMP(4) }
     __shared__ float xch[8][4];
     __shared__ float bc[4][2];
     constexpr int TILE = kBlock * ITEMS;
@@ -516,6 +503,25 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
         return;
     }
     // ---- MODE 0
+    // Which node of the implicit bisection tree is this element the midpoint of (if any, within the
+    // heap depth)?  Index arithmetic only, done in the shadow of the loads.  Down to depth
+    // floor(log2 N) every node is at least two wide, so an element is the midpoint of at most one.
+    int hp_node = 0, hp_depth = 0;
+    if (ITEMS == 1 && d.hpW && base < d.N) {
+        int lo = 0, hi = d.N, t = 1;
+        for (int l = 0; l < d.lh_w; ++l) {
+            const int mid = (lo + hi) >> 1;
+            if (base == mid) {
+                hp_node = t;
+                hp_depth = l;
+                break;
+            }
+            const bool left = base < mid;
+            hi = left ? mid : hi;
+            lo = left ? lo : mid;
+            t = 2 * t + (left ? 0 : 1);
+        }
+    }
     const int b_ref = i_ref / TILE;
     const int rbase = b_ref * TILE + threadIdx.x * ITEMS;
     float wr[ITEMS];
@@ -527,6 +533,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
     float s3[3] = {chunk_total<kTopItems>(pw), chunk_total<kTopItems>(pj), chunk_total<ITEMS>(wv)}, t3[3];
     TreePath p3[3];
     block_upsweep_n<3>(s3, p3, xch[0], t3);
+    FBSMI_STAMP(15)
     // J_prob[i*] = max(1 - sum(J_prob with [i*] = 0), 0)   (resamplings.py:80-82)
     const float Ji = fmaxf(1.0f - t3[1], 0.0f);
     // phase 2: the tile that holds i* (its tree sum changes) and this workgroup's own J tile
@@ -568,6 +575,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
         }
         __syncthreads();
     }
+    FBSMI_STAMP(16)
     float P = bc[0][0], E = bc[0][1];
     float c[ITEMS];
     block_descend(P, E, p3[2]);
@@ -575,6 +583,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
         if (base + i < d.N) d.cdf[base + i] = c[i];
+    if (ITEMS == 1 && hp_node) d.hpW[hp_node] = c[0];
     P = bc[1][0];
     E = bc[1][1];
     block_descend(P, E, p2[1]);
@@ -582,6 +591,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
         if (base + i < d.N) d.cdfJ[base + i] = c[i];
+    if (ITEMS == 1 && hp_node && hp_depth < d.lh_j) d.hpJ[hp_node] = c[0];
     FBSMI_STAMP(5)
 }
 
@@ -591,7 +601,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
 template <int ITEMS, int DMAX>
 __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
-    __shared__ float xch[4];
+    __shared__ float xch[2][4];
     __shared__ float heapW[kHeapSize], heapJ[kHeapSize];
     const int N = d.N;
     const uint32_t* kt = d.keytab + 8 * s;
@@ -640,10 +650,11 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev dd, int s) {
         shift = (j_ref - J) % N;
         if (shift < 0) shift += N;
     }
-    float mloc = -__builtin_inff();
+    float lv[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int m = base + i;
+        lv[i] = -__builtin_inff();
         if (m < N) {
             int src = m - shift;
             if (src < 0) src += N;
@@ -675,142 +686,120 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev dd, int s) {
             // likelihood_logpdf on the gathered particle (csmc.py:145)
             const float l = lg_loglik<DMAX>(t, u, v, v_prev);
             d.lw[m] = l;
-            mloc = fmaxf(mloc, l);
+            lv[i] = l;
         }
     }
-    mloc = block_max4(mloc, xch);
-    if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
+    float mx, sx;
+    block_lse_partial<ITEMS>(lv, xch[0], xch[1], mx, sx);
+    if (threadIdx.x == 0) {
+        d.bmax[blockIdx.x] = mx;
+        d.bsumexp[blockIdx.x] = sx;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-// prop, one slot per thread, latency-optimised.  Work is indexed by the SOURCE slot p: the kill
-// test, the Cat(w) redraw, the ancestor gather, the drift and the log-weight do not depend on the
-// rotation J of the conditional killing (resamplings.py:84-85); only the destination m = p + (j*-J)
-// -- hence the noise index, the pin and the output address -- does.  So the J search and the
-// per-source chain advance together, one shared memory round trip per bisection round.
+// prop, one slot per thread (N <= 131072): the same step as k_lg_prop, arranged around what bounds
+// it -- the number of dependent memory round trips when one chain runs alone, and the number of
+// scattered (one cache line per lane) loads when several chains fill the CUs:
+//   0. everything addressable at entry: the compact heaps the cdf kernel published (coalesced:
+//      2^11 nodes of cdf, 2^8 of cdfJ), tables, the reference row; the slot's own noise is drawn in
+//      the shadow of these loads;
+//   1. J: LDS levels, then the workgroup fetches the remaining interval of cdfJ whole (coalesced);
+//   2. w[src] and the source's own row (a survivor is its own ancestor), rotated but coalesced;
+//   3-4. killed slots only: 11 levels of the Cat(w) search in LDS, the rest three levels per
+//      round trip;  5. killed slots only: the ancestor row.
 // ------------------------------------------------------------------------------------------
 template <int DMAX>
 __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
-    __shared__ float xch[4];
-    __shared__ float heapW[kHeapSize], heapJ[kHeapSize];
+    __shared__ float xch[2][4];
+    __shared__ float heapW[kHeapSizeW], heapJ[kHeapSizeJ];
+    __shared__ float win[kBlock];
     FBSMI_STAMP(6)
     const int N = d.N;
     const uint32_t* kt = d.keytab + 8 * s;
     const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5], t0 = kt[6], t1 = kt[7];
     const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    const bool live = p < N;
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = m < N;
     const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
     float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
-    // ---- round 0: every load whose address is known
+    // ---- round 0
     const float lastJ = d.cdfJ[N - 1];
     const float last = d.cdf[N - 1];
     const float w_max = d.scal[1];
-    const float ws = live ? d.w[p] : 0.0f;
-    float hw = 0.0f, hj = 0.0f;
-    if (threadIdx.x >= 1 && threadIdx.x < kHeapSize) {
-        const int mid = heap_node_mid(threadIdx.x, N);
-        hw = d.cdf[mid];
-        hj = d.cdfJ[mid];
-    }
-    float uref[DMAX], usrc[DMAX];
+    constexpr int kPerThread = kHeapSizeW / kBlock;
+    const int nodesW = 1 << d.lh_w, nodesJ = 1 << d.lh_j;
+    float hw[kPerThread];
 #pragma unroll
-    for (int r = 0; r < DMAX; ++r) {
-        uref[r] = r < d.du ? up[(size_t)r * N + i_ref] : 0.0f;
-        usrc[r] = (r < d.du && live) ? up[(size_t)r * N + p] : 0.0f;   // the ancestor of a survivor is itself
+    for (int h = 0; h < kPerThread; ++h) {
+        const int node = threadIdx.x + h * kBlock;
+        hw[h] = (node >= 1 && node < nodesW) ? d.hpW[node] : 0.0f;
     }
+    const float hj = ((int)threadIdx.x >= 1 && (int)threadIdx.x < nodesJ) ? d.hpJ[threadIdx.x] : 0.0f;
+    float uref[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) uref[r] = r < d.du ? up[(size_t)r * N + i_ref] : 0.0f;
     const StepTables<DMAX> t = step_tables<DMAX>(d, s);
     const float* v_prev = d.vs + (size_t)s * d.dv;
     const float* v = d.vs + (size_t)(s + 1) * d.dv;
     const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
-    // uniforms that depend on nothing in flight
     const float u3 = uniform_at(c0, c1, 1, 0);
-    const float u1 = live ? uniform_at(a0, a1, (uint64_t)N, (uint64_t)p) : 0.0f;
-    const float u2 = live ? uniform_at(b0, b1, (uint64_t)N, (uint64_t)p) : 0.0f;
-    if (threadIdx.x < kHeapSize) {
-        heapW[threadIdx.x] = hw;
-        heapJ[threadIdx.x] = hj;
-    }
+    float xi[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r)
+        xi[r] = (r < d.du && live) ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r) : 0.0f;
+#pragma unroll
+    for (int h = 0; h < kPerThread; ++h) heapW[threadIdx.x + h * kBlock] = hw[h];
+    heapJ[threadIdx.x] = hj;
     FBSMI_STAMP(7)
     __syncthreads();
     FBSMI_STAMP(8)
-    const bool killed = live && (u1 * w_max >= ws);   // resamplings.py:71
-    const float qJ = lastJ * (1.0f - u3);             // :84
-    const float qK = last * (1.0f - u2);              // :73-74
-    BisectCursor cJ, cK;
-    bisect_heap_levels2(N, d.levels, heapJ, qJ, heapW, qK, cJ, cK);
+    // ---- round 1: J = choice(key_3, N, (), p=J_prob) (resamplings.py:84); roll by j - J (:85)
+    const int J = bisect_uniform(d.cdfJ, N, d.levels, d.lh_j, heapJ, win, lastJ * (1.0f - u3));
+    int shift = (j_ref - J) % N;
+    if (shift < 0) shift += N;
+    int src = m - shift;
+    if (src < 0) src += N;
+    if (!live) src = 0;
     FBSMI_STAMP(9)
-    const int Lh = d.levels < kHeapLevels ? d.levels : kHeapLevels;
-    const float* __restrict__ cdfJ = d.cdfJ;
-    const float* __restrict__ cdfW = d.cdf;
-#pragma unroll 1
-    for (int rem = d.levels - Lh; rem > 0; rem -= 3) {
-        // the 7 candidate positions of the next three levels, for both searches; issue all loads,
-        // wait once, then walk both
-        const int jl = cJ.lo, jh = cJ.hi, kl = cK.lo, kh = cK.hi;
-        const int j1 = (jl + jh) >> 1, j2l = (jl + j1) >> 1, j2r = (j1 + jh) >> 1;
-        const int j3a = (jl + j2l) >> 1, j3b = (j2l + j1) >> 1, j3c = (j1 + j2r) >> 1, j3d = (j2r + jh) >> 1;
-        const int k1 = (kl + kh) >> 1, k2l = (kl + k1) >> 1, k2r = (k1 + kh) >> 1;
-        const int k3a = (kl + k2l) >> 1, k3b = (k2l + k1) >> 1, k3c = (k1 + k2r) >> 1, k3d = (k2r + kh) >> 1;
-        const float vj1 = cdfJ[j1], vj2l = cdfJ[j2l], vj2r = cdfJ[j2r];
-        const float vj3a = cdfJ[j3a], vj3b = cdfJ[j3b], vj3c = cdfJ[j3c], vj3d = cdfJ[j3d];
-        float vk1 = 0.f, vk2l = 0.f, vk2r = 0.f, vk3a = 0.f, vk3b = 0.f, vk3c = 0.f, vk3d = 0.f;
-        if (killed) {
-            vk1 = cdfW[k1]; vk2l = cdfW[k2l]; vk2r = cdfW[k2r];
-            vk3a = cdfW[k3a]; vk3b = cdfW[k3b]; vk3c = cdfW[k3c]; vk3d = cdfW[k3d];
-        }
-        {
-            int lo = jl, hi = jh;
-            const bool g1 = qJ <= vj1;
-            hi = g1 ? j1 : hi; lo = g1 ? lo : j1;
-            const int m2 = g1 ? j2l : j2r;
-            const bool g2 = qJ <= (g1 ? vj2l : vj2r);
-            hi = g2 ? m2 : hi; lo = g2 ? lo : m2;
-            const int m3 = g1 ? (g2 ? j3a : j3b) : (g2 ? j3c : j3d);
-            const bool g3 = qJ <= (g1 ? (g2 ? vj3a : vj3b) : (g2 ? vj3c : vj3d));
-            hi = g3 ? m3 : hi; lo = g3 ? lo : m3;
-            cJ.lo = lo; cJ.hi = hi;
-        }
-        {
-            int lo = kl, hi = kh;
-            const bool g1 = qK <= vk1;
-            hi = g1 ? k1 : hi; lo = g1 ? lo : k1;
-            const int m2 = g1 ? k2l : k2r;
-            const bool g2 = qK <= (g1 ? vk2l : vk2r);
-            hi = g2 ? m2 : hi; lo = g2 ? lo : m2;
-            const int m3 = g1 ? (g2 ? k3a : k3b) : (g2 ? k3c : k3d);
-            const bool g3 = qK <= (g1 ? (g2 ? vk3a : vk3b) : (g2 ? vk3c : vk3d));
-            hi = g3 ? m3 : hi; lo = g3 ? lo : m3;
-            cK.lo = lo; cK.hi = hi;
-        }
-    }
-    FBSMI_STAMP(10)
-    const int a = killed ? cK.hi : p;
-    // ancestor gather (only killed slots need a second load)
+    // ---- round 2
+    const float ws = d.w[src];
     float u[DMAX];
 #pragma unroll
-    for (int r = 0; r < DMAX; ++r) u[r] = (r < d.du && killed) ? up[(size_t)r * N + a] : usrc[r];
-    // destination slot
-    int shift = (j_ref - cJ.hi) % N;   // roll by j - J (:85)
-    if (shift < 0) shift += N;
-    int m = p + shift;
-    if (m >= N) m -= N;
-    const bool pinned = live && m == j_ref;   // idx[j] = i (:86) and us[b*] = u* (csmc.py:143)
+    for (int r = 0; r < DMAX; ++r) u[r] = r < d.du ? up[(size_t)r * N + src] : 0.0f;
+    const float u1 = uniform_at(a0, a1, (uint64_t)N, (uint64_t)src);
+    const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)src);
+    const float qK = last * (1.0f - u2);                                    // resamplings.py:73-74
+    int lo, hi;
+    bisect_lds_levels(N, d.lh_w, heapW, qK, lo, hi);
+    const bool killed = live && (u1 * w_max >= ws);                         // :71
+    FBSMI_STAMP(10)
+    // ---- rounds 3, 4
+#pragma unroll 1
+    for (int rem = d.levels - d.lh_w; rem > 0; rem -= 3) bisect_round3(d.cdf, lo, hi, qK, killed);
+    const bool pinned = m == j_ref;
+    const int a = pinned ? i_ref : (killed ? hi : src);                     // :86
+    FBSMI_STAMP(11)
+    // ---- round 5
+    if (killed && !pinned) {
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r)
+            if (r < d.du) u[r] = up[(size_t)r * N + a];
+    }
     if (pinned) {
 #pragma unroll
         for (int r = 0; r < DMAX; ++r) u[r] = uref[r];
     }
-    FBSMI_STAMP(11)
-    float mloc = -__builtin_inff();
+    float lv[1] = {-__builtin_inff()};
     if (live) {
-        if (d.As) d.As[(size_t)s * N + m] = pinned ? i_ref : a;
+        if (d.As) d.As[(size_t)s * N + m] = a;
+        // transition_sampler (gp_gibbs.py:120-122) and the pin of csmc.py:143
 #pragma unroll
         for (int r = 0; r < DMAX; ++r) {
             if (r < d.du) {
                 const float dr = drift_row<DMAX>(t, r, u, v_prev);
-                const float xi = normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r);
-                float x = (u[r] + dr * t.dt) + t.sd * xi;
+                float x = (u[r] + dr * t.dt) + t.sd * xi[r];
                 if (pinned) x = ustar[r];
                 un[(size_t)r * N + m] = x;
                 if (d.uss) d.uss[((size_t)(s + 1) * N + m) * d.du + r] = x;
@@ -818,19 +807,23 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
         }
         const float l = lg_loglik<DMAX>(t, u, v, v_prev);   // likelihood_logpdf on the gathered particle (csmc.py:145)
         d.lw[m] = l;
-        mloc = l;
+        lv[0] = l;
     }
     FBSMI_STAMP(12)
-    mloc = block_max4(mloc, xch);
-    if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
+    float mx, sx;
+    block_lse_partial<1>(lv, xch[0], xch[1], mx, sx);
+    if (threadIdx.x == 0) {
+        d.bmax[blockIdx.x] = mx;
+        d.bsumexp[blockIdx.x] = sx;
+    }
     FBSMI_STAMP(13)
 }
 
 // ------------------------------------------------------------------------------------------
 // Fused particle filters for the analytic model: bootstrap_filter (fbs/samplers/smc.py:9-88) and
 // pmcmc_filter_step (smc.py:115-158) with stratified / systematic resampling
-// (fbs/samplers/resampling.py:43-59).  Same four dependency levels per step as the Gibbs sweep:
-//   sumexp -> fnorm (lse, w, log-likelihood accumulator, partials of w) -> cdf -> fprop.
+// (fbs/samplers/resampling.py:43-59).  Same three dependency levels per step as the Gibbs sweep:
+//   fnorm (lse, w, log-likelihood accumulator, partials of w) -> cdf -> fprop (+ per-workgroup (max, sumexp)).
 // The two functions order a step differently:
 //   bootstrap : propagate(us_prev) ; weight(us_prev) ; resample the NEW particles
 //               => fprop(k) = [resample with step k-1's weights] gather, propagate, weight (old)
@@ -858,14 +851,15 @@ __global__ void __launch_bounds__(kBlock) k_filt_keys(LgDev dd) {
 template <int ITEMS, int DMAX>
 __global__ void __launch_bounds__(kBlock) k_filt_init(LgDev dd, const float* u0s_all) {
     const LgDev d = chain_view(dd, blockIdx.y);
-    __shared__ float xch[4];
+    __shared__ float xch[2][4];
     const float* u0s = u0s_all + (size_t)blockIdx.y * d.N * d.du;
     const StepTables<DMAX> t = step_tables<DMAX>(d, 0);
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
-    float mloc = -__builtin_inff();
+    float lv[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int p = base + i;
+        lv[i] = -__builtin_inff();
         if (p < d.N) {
             float u[DMAX];
 #pragma unroll
@@ -879,13 +873,17 @@ __global__ void __launch_bounds__(kBlock) k_filt_init(LgDev dd, const float* u0s
             if (d.flow == 1) {
                 const float l = lg_loglik<DMAX>(t, u, d.vs + d.dv, d.vs);   // smc.py:144, k = 0
                 d.lw[p] = l;
-                mloc = fmaxf(mloc, l);
+                lv[i] = l;
             }
         }
     }
     if (d.flow == 1) {
-        mloc = block_max4(mloc, xch);
-        if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
+        float mx, sx;
+        block_lse_partial<ITEMS>(lv, xch[0], xch[1], mx, sx);
+        if (threadIdx.x == 0) {
+            d.bmax[blockIdx.x] = mx;
+            d.bsumexp[blockIdx.x] = sx;
+        }
     }
 }
 
@@ -898,15 +896,8 @@ __global__ void __launch_bounds__(kBlock) k_filt_norm(LgDev dd) {
     float l[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) l[i] = base + i < d.N ? d.lw[base + i] : 0.0f;
-    float bs4[kTopItems];
-    top_load(d.bsumexp, d.nb, bs4);
-    float mloc = wave_max(top_load_max(d.bmax, d.nb));
-    if ((threadIdx.x & 63) == 0) xch[0][threadIdx.x >> 6] = mloc;
-    float sv[1] = {chunk_total<kTopItems>(bs4)}, tot[1];
-    TreePath tp[1];
-    block_upsweep_n<1>(sv, tp, xch[1], tot);
-    const float Mraw = fmaxf(fmaxf(xch[0][0], xch[0][1]), fmaxf(xch[0][2], xch[0][3]));
-    const float c = fbsmi_logf(tot[0]) + finite_or_zero(Mraw);
+    float c, Mraw;
+    lse_from_partials(d.bmax, d.bsumexp, d.nb, xch[0], xch[1], c, Mraw);
     float xw[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -939,7 +930,7 @@ template <int ITEMS, int DMAX>
 __global__ void __launch_bounds__(kBlock) k_filt_prop(LgDev dd, int s, int resample, int kres, int weight,
                                                       int propagate) {
     const LgDev d = chain_view(dd, blockIdx.y);
-    __shared__ float xch[4];
+    __shared__ float xch[2][4];
     __shared__ float heapW[kHeapSize];
     const int N = d.N;
     const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
@@ -959,10 +950,11 @@ __global__ void __launch_bounds__(kBlock) k_filt_prop(LgDev dd, int s, int resam
     const StepTables<DMAX> t = step_tables<DMAX>(d, st);
     const StepTables<DMAX> tn = step_tables<DMAX>(d, st + 1 < d.T ? st + 1 : st);
     const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
-    float mloc = -__builtin_inff();
+    float lv[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int m = base + i;
+        lv[i] = -__builtin_inff();
         if (m < N) {
             int a = m;
             if (resample) {   // _systematic_or_stratified, resampling.py:43-51
@@ -1003,17 +995,21 @@ __global__ void __launch_bounds__(kBlock) k_filt_prop(LgDev dd, int s, int resam
             if (weight == 1) {         // measurement_cond_pdf(v, us_prev, v_prev, t_prev)      smc.py:65
                 const float l = lg_loglik<DMAX>(t, u, d.vs + (size_t)(s + 1) * d.dv, d.vs + (size_t)s * d.dv);
                 d.lw[m] = l;
-                mloc = fmaxf(mloc, l);
+                lv[i] = l;
             } else if (weight == 2) {  // next step's likelihood_logpdf on the propagated particle  smc.py:144
                 const float l = lg_loglik<DMAX>(tn, x, d.vs + (size_t)(s + 2) * d.dv, d.vs + (size_t)(s + 1) * d.dv);
                 d.lw[m] = l;
-                mloc = fmaxf(mloc, l);
+                lv[i] = l;
             }
         }
     }
     if (weight) {
-        mloc = block_max4(mloc, xch);
-        if (threadIdx.x == 0) d.bmax[blockIdx.x] = mloc;
+        float mx, sx;
+        block_lse_partial<ITEMS>(lv, xch[0], xch[1], mx, sx);
+        if (threadIdx.x == 0) {
+            d.bmax[blockIdx.x] = mx;
+            d.bsumexp[blockIdx.x] = sx;
+        }
     }
 }
 
@@ -1120,11 +1116,11 @@ struct fbsmi_lg_sweep {
     hipGraphExec_t graph_single = nullptr;  // one sweep, no chain bookkeeping
     hipGraphExec_t graph_chain = nullptr;   // one sweep + key split + advance
     bool profile = false;
-    bool legacy_prop = false;  // FBSMI_LEGACY_PROP=1: per-destination prop kernel also for one slot per thread
-    int debug_mask = 15;  // FBSMI_DEBUG_STEP_MASK: bit0 norm, bit1 cdf, bit2 prop, bit3 sumexp (timing experiments only)
+    bool generic_prop = false;  // FBSMI_GENERIC_PROP=1: k_lg_prop also for one slot per thread (timing experiments)
+    int debug_mask = 7;  // FBSMI_DEBUG_STEP_MASK: bit0 norm, bit1 cdf, bit2 prop (timing experiments only)
     std::vector<hipEvent_t> prof_ev[kNumProfKernels];  // pairs (start, stop)
-    double prof_us[kNumProfKernels] = {0, 0, 0, 0};
-    int64_t prof_n[kNumProfKernels] = {0, 0, 0, 0};
+    double prof_us[kNumProfKernels] = {0, 0, 0};
+    int64_t prof_n[kNumProfKernels] = {0, 0, 0};
 };
 
 namespace {
@@ -1197,10 +1193,6 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     k_lg_path<<<dim3(gpath, d.C), 64, 0, st>>>(d, 0);
     LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d)));
     for (int k = 0; k < d.T; ++k) {
-        if (s->debug_mask & 8) {
-            ProfScope p(s, 3, st);
-            LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<gtile, kBlock, 0, st>>>(d)));
-        }
         if (s->debug_mask & 1) {
             ProfScope p(s, 0, st);
             LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 0><<<gtile, kBlock, 0, st>>>(d, k)));
@@ -1211,14 +1203,13 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
         }
         if (s->debug_mask & 4) {
             ProfScope p(s, 2, st);
-            if (s->items == 1 && !s->legacy_prop) {
+            if (s->items == 1 && s->dmax <= 16 && !s->generic_prop) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
             } else {
                 LG_DISPATCH(s, (k_lg_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
             }
         }
     }
-    LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<gtile, kBlock, 0, st>>>(d)));
     if (d.eb) {
         LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 1><<<gtile, kBlock, 0, st>>>(d, d.T)));
         LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 1><<<gtile, kBlock, 0, st>>>(d, d.T)));
@@ -1322,8 +1313,8 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     d.G = m->G; d.g = m->g; d.sd = m->sd; d.lognorm = m->lognorm; d.F = m->F; d.sqQ = m->sqQ;
     d.levels = bisect_levels(d.N);
     if (const char* dm = getenv("FBSMI_DEBUG_STEP_MASK")) s->debug_mask = atoi(dm);
-    if (const char* lp = getenv("FBSMI_LEGACY_PROP")) s->legacy_prop = atoi(lp) != 0;
-    s->items = d.N <= (1 << 17) ? 1 : (d.N <= (1 << 20) ? 4 : 16);
+    if (const char* gp = getenv("FBSMI_GENERIC_PROP")) s->generic_prop = atoi(gp) != 0;
+    s->items = fbsmi_tile_items(d.N);  // one workgroup = one tile of the two-level logsumexp (include/fbsmi_math.h)
     const int maxd = m->du > m->dv ? m->du : m->dv;
     s->dmax = maxd <= 2 ? 2 : (maxd <= 4 ? 4 : 16);
     const int tile = kBlock * s->items;
@@ -1362,6 +1353,16 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     rc |= dev_alloc(s, &d.cdfJ, C * N);
     rc |= dev_alloc(s, &d.bmax, C * d.nb);
     rc |= dev_alloc(s, &d.bsumexp, C * d.nb);
+    d.hpW = d.hpJ = nullptr;
+    d.lh_w = d.lh_j = 0;
+    if (s->items == 1) {
+        int fl = 0;
+        while ((2ll << fl) <= (long long)d.N) ++fl;   // floor(log2 N)
+        d.lh_w = fl < kHeapLevelsW ? fl : kHeapLevelsW;
+        d.lh_j = fl < kHeapLevelsJ ? fl : kHeapLevelsJ;
+        rc |= dev_alloc(s, &d.hpW, C * (size_t)kHeapSizeW);
+        rc |= dev_alloc(s, &d.hpJ, C * (size_t)kHeapSizeJ);
+    }
     rc |= dev_alloc(s, &d.bsumw, C * d.nb);
     rc |= dev_alloc(s, &d.bsumJ, C * d.nb);
     rc |= dev_alloc(s, &d.scal, C * 16);
@@ -1509,7 +1510,6 @@ int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
     for (int k = 0; k < d.T; ++k) {
         if (d.flow == 0)
             LG_DISPATCH(s, (k_filt_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k, k > 0, k > 0 ? k - 1 : 0, 1, 1)));
-        LG_DISPATCH(s, (void)DMAX; (k_lg_sumexp<ITEMS><<<gtile, kBlock, 0, st>>>(d)));
         LG_DISPATCH(s, (void)DMAX; (k_filt_norm<ITEMS><<<gtile, kBlock, 0, st>>>(d)));
         LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 2><<<gtile, kBlock, 0, st>>>(d, d.T)));
         if (d.flow == 1)

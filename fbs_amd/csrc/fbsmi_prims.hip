@@ -403,6 +403,43 @@ __global__ void k_backtrace(const int32_t* As, int32_t T, int32_t n, const int32
     }
 }
 
+// two-level logsumexp (include/fbsmi_math.h): per-tile (max, sumexp) ...
+template <int ITEMS>
+__global__ void __launch_bounds__(kBlock) k_part_lse(const float* x, int64_t n, float* pmax, float* psum) {
+    __shared__ float xch[2][4];
+    const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    float l[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) l[i] = base + i < n ? x[base + i] : -__builtin_inff();
+    float m, sx;
+    block_lse_partial<ITEMS>(l, xch[0], xch[1], m, sx);
+    if (threadIdx.x == 0) {
+        pmax[blockIdx.x] = m;
+        psum[blockIdx.x] = sx;
+    }
+}
+
+// ... combined by one workgroup: out[0] = log(tree-sum_t s_t exp(m_t' - M')) + M'  (dynamic LDS: nbp floats)
+__global__ void __launch_bounds__(kBlock) k_lse_top(const float* pmax, const float* psum, int nb, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float s4[4];
+    float m = -__builtin_inff();
+    for (int i = threadIdx.x; i < nb; i += kBlock) m = fmaxf(m, pmax[i]);
+    const float Mp = finite_or_zero(block_max(m, s4));
+    const int nbp = next_pow2(nb);
+    for (int i = threadIdx.x; i < nbp; i += kBlock)
+        lds[i] = i < nb ? psum[i] * fbsmi_expf(finite_or_zero(pmax[i]) - Mp) : 0.0f;
+    __syncthreads();
+    for (int d = 1; d < nbp; d <<= 1) {
+        for (int i = threadIdx.x; i < nbp / (2 * d); i += kBlock) {
+            const int r = (i + 1) * 2 * d - 1;
+            lds[r] = lds[r - d] + lds[r];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = fbsmi_logf(lds[nbp - 1]) + Mp;
+}
+
 // ------------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------------
@@ -413,7 +450,7 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
     return (int)g;
 }
 
-int items_for(int64_t n) { return n <= 65536 ? 1 : (n <= (1ll << 22) ? 4 : 16); }
+int items_for(int64_t n) { return fbsmi_tile_items(n); }  // the tile rule of include/fbsmi_math.h
 
 Workspace carve(void* ws, int64_t n) {
     Workspace W;
@@ -514,16 +551,11 @@ static ValArgs plain(const float* x, int64_t n) {
 }
 
 int logsumexp_impl(const float* x, int64_t n, float* out, Workspace& W, hipStream_t st) {
-    const int nbm = launch_part_max(x, n, W.part1, st);
-    ValArgs a = plain(x, n);
-    a.partmax = W.part1;
-    a.nbmax = nbm;
-    const int nb = launch_part_sum<V_EXPSHIFT>(a, W.part0, st);
-    TopRef top;
-    int rc = make_top(W.part0, nb, nullptr, nullptr, W.scal + 60, st, &top);
-    if (rc) return rc;
-    if (top.root) top.pref = top.pend = W.scal + 60;
-    k_lse_final<<<1, kBlock, 0, st>>>(W.part1, top, out);
+    const int items = items_for(n);
+    const int nb = (int)((n + (int64_t)kBlock * items - 1) / ((int64_t)kBlock * items));
+    if (nb > kMaxTopLds) return fail(FBSMI_ERR_UNSUPPORTED, "logsumexp: too many elements for the top-level tree");
+    FBSMI_DISPATCH_ITEMS(items, (k_part_lse<ITEMS><<<nb, kBlock, 0, st>>>(x, n, W.part1, W.part0)));
+    k_lse_top<<<1, kBlock, sizeof(float) * next_pow2(nb), st>>>(W.part1, W.part0, nb, out);
     FBSMI_LAUNCH_CHECK();
     return FBSMI_OK;
 }

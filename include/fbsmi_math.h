@@ -172,6 +172,17 @@ FBSMI_HD float fbsmi_bits_to_normal(uint32_t bits) {
     return 1.41421354f * fbsmi_erfinvf(u);
 }
 
+/* ---- summation / logsumexp layout -----------------------------------------------------------------
+ * Sums follow one tree over the element index (see fbs_amd/csrc/fbsmi_device.h).  logsumexp is
+ * TWO-LEVEL so that it needs one grid-wide dependency instead of two: the input is cut into tiles of
+ * fbsmi_tile(n) consecutive elements; tile t has m_t = max, m_t' = (m_t finite ? m_t : 0) and
+ * s_t = tree-sum_i exp(x_i - m_t'); then M = max_t m_t, M' = (M finite ? M : 0),
+ *     logsumexp(x) = log( tree-sum_t  s_t * exp(m_t' - M') ) + M'.
+ * For n <= fbsmi_tile(n) (one tile) this is exactly jax.scipy.special.logsumexp's
+ * max / exp / sum / log; for larger n it differs from it by rounding only. */
+FBSMI_HD int fbsmi_tile_items(long long n) { return n <= 131072 ? 1 : (n <= 1048576 ? 4 : 16); }
+FBSMI_HD int fbsmi_tile(long long n) { return 256 * fbsmi_tile_items(n); }
+
 #if !defined(__clang__) && defined(__GNUC__)
 #pragma GCC pop_options
 #endif

@@ -228,16 +228,31 @@ ORC_API void orc_choice(const uint32_t key[2], const float* w, int32_t n, int64_
     free(u);
 }
 
-/* jax.scipy.special.logsumexp */
+/* jax.scipy.special.logsumexp in the two-level form specified in include/fbsmi_math.h (identical to
+ * max / exp / sum / log when the input fits one tile). */
 ORC_API float orc_logsumexp(const float* x, int64_t n) {
-    float m = orc_max(x, n);
-    if (!(fabsf(m) <= 3.40282347e+38f)) m = 0.0f;
-    float* e = (float*)malloc(sizeof(float) * (size_t)n);
-    ORC_PARALLEL_FOR
-    for (int64_t i = 0; i < n; ++i) e[i] = fbsmi_expf(x[i] - m);
-    const float s = orc_sum(e, n);
+    const int64_t tile = fbsmi_tile(n);
+    const int64_t nt = (n + tile - 1) / tile;
+    float* tm = (float*)malloc(sizeof(float) * (size_t)nt);
+    float* ts = (float*)malloc(sizeof(float) * (size_t)nt);
+    float* e = (float*)malloc(sizeof(float) * (size_t)(tile < n ? tile : n));
+    float M = -INFINITY;
+    for (int64_t t = 0; t < nt; ++t) {
+        const int64_t lo = t * tile, cnt = (lo + tile <= n ? tile : n - lo);
+        float m = orc_max(x + lo, cnt);
+        M = m > M ? m : M;
+        if (!(fabsf(m) <= 3.40282347e+38f)) m = 0.0f;
+        for (int64_t i = 0; i < cnt; ++i) e[i] = fbsmi_expf(x[lo + i] - m);
+        tm[t] = m;
+        ts[t] = orc_sum(e, cnt);
+    }
+    if (!(fabsf(M) <= 3.40282347e+38f)) M = 0.0f;
+    for (int64_t t = 0; t < nt; ++t) ts[t] = ts[t] * fbsmi_expf(tm[t] - M);
+    const float S = orc_sum(ts, nt);
+    free(tm);
+    free(ts);
     free(e);
-    return fbsmi_logf(s) + m;
+    return fbsmi_logf(S) + M;
 }
 
 /* csmc.normalise (fbs/samplers/csmc/csmc.py:273-292) */

@@ -24,11 +24,12 @@ int main(int argc, char** argv) {
     fbsmi_lg_sweep_view(s, 7, d, &cnt, st); (void)hipStreamSynchronize(st);
     unsigned long long h[64]; (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     auto rt = [&](int i) { return (double)h[2 * i] * 10.0; };   // ns
-    const char* names[] = {"sumexp in", "sumexp out", "norm in", "norm out", "cdf in", "cdf out", "prop in", "prop r0 issued+ALU",
-                           "prop heap barrier", "prop LDS levels", "prop global rounds", "prop gather+dest", "prop compute+store", "prop out"};
-    // order of the last step: norm(2,3) cdf(4,5) prop(6..13) then the trailing sumexp(0,1)
+    const char* names[] = {"", "", "norm in", "norm out", "cdf in", "cdf out", "prop in", "prop r0 issued+ALU", "prop heap barrier",
+                           "prop J found", "prop w[src], LDS levels", "prop K rounds", "prop gather+compute+store", "prop out",
+                           "norm lse known", "cdf phase 1 (loads, exchange)", "cdf tile (P,E) known"};
+    // the last step of the loop: norm(2,14,3) cdf(4,15,16,5) prop(6..13)
     double t0 = rt(2);
-    int order[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1};
+    int order[] = {2, 14, 3, 4, 15, 16, 5, 6, 7, 8, 9, 10, 11, 12, 13};
     double prev = t0;
     for (int i : order) { printf("%-22s t=%8.0f ns  (+%6.0f)\n", names[i], rt(i) - t0, rt(i) - prev); prev = rt(i); }
     double dclk = (double)(h[2 * 13 + 1] - h[2 * 6 + 1]), dns = rt(13) - rt(6);
