@@ -188,7 +188,11 @@ def main():
             h = br.host
             om = O.LGModel(br.du, br.dv, br.dt, h["G"], h["g"], h["sd"], h["lognorm"], h["F"], h["sqQ"])
             nthreads = max(1, min(os.cpu_count() or 1, 16))
-            sweeps = max(args.cpu_sweeps, 2 if nthreads == 1 else 6)
+            # bounded sample: one probing sweep sizes the timed run to about 15 s of CPU work
+            p0 = time.perf_counter()
+            O.bench_gibbs_lg(om, 665, np.zeros(1, np.float32), y0, N, 1, threads=nthreads)
+            probe = time.perf_counter() - p0
+            sweeps = max(args.cpu_sweeps, min(64, int(15.0 / max(probe, 1e-3))))
             c0 = time.perf_counter()
             _, used = O.bench_gibbs_lg(om, 666, np.zeros(1, np.float32), y0, N, sweeps, threads=nthreads)
             cdt = time.perf_counter() - c0

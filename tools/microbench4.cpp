@@ -13,17 +13,27 @@ int main(int argc, char** argv) {
         sd[k] = 0.0632f; ln[k] = logf(6.2831853f * sd[k] * sd[k]); F[k] = 0.998f; sq[k] = 0.0632f; }
     auto up = [](const std::vector<float>& v) { float* p; (void)hipMalloc(&p, v.size() * 4); (void)hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice); return p; };
     fbsmi_lg_model m{1, 1, T, 2.0f / T, up(G), up(g), up(sd), up(ln), up(F), up(sq)};
-    fbsmi_lg_sweep* s = nullptr;
-    if (fbsmi_lg_sweep_create(&m, N, 1, 0, 0, C, &s)) { printf("create failed: %s\n", fbsmi_last_error()); return 1; }
-    uint32_t* key; float *x0, *y0; int32_t* bs;
-    (void)hipMalloc(&key, 8); (void)hipMalloc(&x0, 4 * C); (void)hipMalloc(&y0, 4); (void)hipMalloc(&bs, (T + 1) * 4 * C);
-    (void)hipMemset(key, 1, 8); (void)hipMemset(x0, 0, 4 * C); (void)hipMemset(y0, 0, 4); (void)hipMemset(bs, 0, (T + 1) * 4 * C);
-    hipStream_t st; (void)hipStreamCreate(&st);
-    fbsmi_lg_gibbs_chain(s, key, x0, y0, bs, 2, nullptr, 1, st); (void)hipStreamSynchronize(st);
+    const int H = argc > 3 ? atoi(argv[3]) : 1;   // independent handles driven concurrently, each on its own stream
+    std::vector<fbsmi_lg_sweep*> hs(H, nullptr);
+    std::vector<hipStream_t> sts(H);
+    std::vector<uint32_t*> keys(H);
+    float *x0, *y0; int32_t* bs;
+    (void)hipMalloc(&x0, 4 * C); (void)hipMalloc(&y0, 4); (void)hipMalloc(&bs, (T + 1) * 4 * C);
+    (void)hipMemset(x0, 0, 4 * C); (void)hipMemset(y0, 0, 4); (void)hipMemset(bs, 0, (T + 1) * 4 * C);
+    for (int h = 0; h < H; ++h) {
+        if (fbsmi_lg_sweep_create(&m, N, 1, 0, 0, C, &hs[h])) { printf("create failed: %s\n", fbsmi_last_error()); return 1; }
+        (void)hipStreamCreateWithFlags(&sts[h], hipStreamNonBlocking);
+        (void)hipMalloc(&keys[h], 8); (void)hipMemset(keys[h], 1 + h, 8);
+    }
+    (void)hipDeviceSynchronize();
+    for (int h = 0; h < H; ++h) fbsmi_lg_gibbs_chain(hs[h], keys[h], x0, y0, bs, 2, nullptr, 1, sts[h]);
+    (void)hipDeviceSynchronize();
     auto t0 = std::chrono::steady_clock::now();
-    fbsmi_lg_gibbs_chain(s, key, x0, y0, bs, 10, nullptr, 1, st); (void)hipStreamSynchronize(st);
+    for (int it = 0; it < 10; ++it)
+        for (int h = 0; h < H; ++h) fbsmi_lg_gibbs_chain(hs[h], keys[h], x0, y0, bs, 1, nullptr, 1, sts[h]);
+    (void)hipDeviceSynchronize();
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 10;
-    printf("bare C++ host, mask %s, N=%d, chains=%d: %.3f ms/sweep = %.2f us/step = %.3f G particle-steps/s\n", getenv("FBSMI_DEBUG_STEP_MASK") ? getenv("FBSMI_DEBUG_STEP_MASK") : "15", N, C, dt * 1e3, dt / T * 1e6, (double)N * T * C / dt / 1e9);
-    fbsmi_lg_sweep_destroy(s);
+    printf("bare C++ host, N=%d, chains/handle=%d, concurrent handles=%d: %.3f ms/sweep = %.2f us/step = %.3f G particle-steps/s\n", N, C, H, dt * 1e3, dt / T * 1e6, (double)N * T * C * H / dt / 1e9);
+    for (auto h : hs) fbsmi_lg_sweep_destroy(h);
     return 0;
 }

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun) from the repo root:  bash tools/profile_round.sh r01
+# Produces gpurun_out/<tag>_*: the bench line, the rocprofv3 kernel-trace statistics of the same
+# command, and two separate PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass).
+# tools/summarise_profiles.py then condenses them into profiles/.
+set -e
+tag=${1:-r01}
+out=$PWD/gpurun_out
+export TMPDIR=/tmp
+python3 bench.py > $out/${tag}_bench_stdout.json 2> $out/${tag}_bench_stderr.log
+tail -c 600 $out/${tag}_bench_stdout.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o run -- python3 bench.py --no-cpu-baseline --no-single-chain --batch-scan "" > $out/${tag}_prof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" > $out/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" > $out/${tag}_pmc_write.log 2>&1
+find $out/${tag}_prof $out/${tag}_pmc_fetch $out/${tag}_pmc_write -name "*.csv" | head -20
+# keep the merge-back small: the raw traces are large
+find $out/${tag}_prof -name "*kernel_trace.csv" -delete

@@ -1,0 +1,81 @@
+"""Condense the rocprofv3 output of tools/profile_round.sh (under gpurun_out/) into profiles/.
+
+    python tools/summarise_profiles.py r01
+
+writes profiles/<tag>_bench_stdout.json, <tag>_bench_kernel_stats.csv (rocprofv3 --stats, verbatim),
+<tag>_bench_pmc_fetch_write.csv (per-kernel averages of the two PMC passes) and
+<tag>_pmc_traffic.json (the prop kernel's HBM-side bytes per launch, read by bench.py)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(ROOT, "gpurun_out", pattern), recursive=True)
+    if not hits:
+        raise SystemExit(f"nothing matches gpurun_out/{pattern}")
+    return sorted(hits)[-1]
+
+
+def pmc_avgs(path, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] != counter:
+            continue
+        a = acc[row["Kernel_Name"]]
+        a[0] += float(row["Counter_Value"])
+        a[1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    prof = os.path.join(ROOT, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    line = [l for l in open(one(f"{tag}_bench_stdout.json")) if l.startswith("{")][-1]
+    bench = json.loads(line)
+    json.dump(bench, open(os.path.join(prof, f"{tag}_bench_stdout.json"), "w"), indent=1)
+    shutil.copy(one(f"{tag}_prof/**/*kernel_stats.csv"), os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
+    try:
+        shutil.copy(one(f"{tag}_prof/**/*domain_stats.csv"), os.path.join(prof, f"{tag}_bench_domain_stats.csv"))
+    except SystemExit:
+        pass
+    fetch = pmc_avgs(one(f"{tag}_pmc_fetch/**/*counter_collection.csv"), "FETCH_SIZE")
+    write = pmc_avgs(one(f"{tag}_pmc_write/**/*counter_collection.csv"), "WRITE_SIZE")
+    with open(os.path.join(prof, f"{tag}_bench_pmc_fetch_write.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "launches"])
+        for k in sorted(set(fetch) | set(write)):
+            w.writerow([k, fetch.get(k, (0, 0))[0], write.get(k, (0, 0))[0], max(fetch.get(k, (0, 0))[1], write.get(k, (0, 0))[1])])
+    cfg = bench["config"]
+    prop = [k for k in fetch if "k_lg_prop" in k]
+    if not prop:
+        raise SystemExit("no k_lg_prop kernel in the PMC pass")
+    k = max(prop, key=lambda n: fetch[n][1])
+    fkb, wkb = fetch[k][0], write.get(k, (0.0, 0))[0]
+    traffic = {
+        "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
+                   "--steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan ''",
+        "workload": cfg.get("workload"),
+        "kernel": k,
+        "k_lg_prop_FETCH_SIZE_KB": fkb,
+        "k_lg_prop_WRITE_SIZE_KB": wkb,
+        "k_lg_prop_bytes_per_launch": (fkb + wkb) * 1024.0,
+        "algorithmic_bytes_per_launch": bench["roofline"]["bytes_per_launch"],
+        "note": "Raw counters (KB = 1024 B), no gfx950 x2 FETCH correction applied: the guide calibrates that "
+                "correction for 16-B-per-lane streaming reads, these kernels move 4 B per lane.  The counters sit on "
+                "the memory side of the XCD L2s (Infinity-Cache hits included).",
+    }
+    json.dump(traffic, open(os.path.join(prof, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
+    print(open(os.path.join(prof, f"{tag}_bench_kernel_stats.csv")).read()[:1500])
+
+
+if __name__ == "__main__":
+    main()
