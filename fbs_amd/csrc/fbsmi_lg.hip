@@ -71,6 +71,9 @@ struct LgDev {
     float* cdfJ;       // [N]
     float *bmax, *bsumexp, *bsumw, *bsumJ;  // [nb]
     float *hpW, *hpJ;                       // compact bisection heaps of cdf / cdfJ (one slot per thread only)
+    int wide;                               // 16 < max(du, dv) <= 128: row-major particles u0/u1 [N][du], MFMA drift
+    float* lpw;                             // [dv][N] per-row log-density terms of the wide path
+    int32_t* anc;                           // [N] ancestors of the current step (wide path)
     int lh_w, lh_j;                         // their depths
     float* scal;       // [16]: 0 lse, 1 w_max
     int32_t* As;       // [T][N] or null
@@ -132,6 +135,10 @@ __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
     d.bsumexp += nb * c;
     d.bsumw += nb * c;
     d.bsumJ += nb * c;
+    if (d.lpw) {
+        d.lpw += dv * N * c;
+        d.anc += N * c;
+    }
     if (d.hpW) {
         d.hpW += (size_t)kHeapSizeW * c;
         d.hpJ += (size_t)kHeapSizeJ * c;
@@ -147,6 +154,12 @@ __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
     d.acc += (T + 1) * c;
     if (d.ell) d.ell += c;
     return d;
+}
+
+// element (row r, slot p) of a particle buffer: structure-of-arrays [du][N] for narrow models (every
+// per-slot access coalesced), row-major [N][du] for wide ones (the ancestor gather moves whole rows)
+__device__ __forceinline__ size_t u_at(const LgDev& d, int r, int p) {
+    return d.wide ? (size_t)p * d.du + r : (size_t)r * d.N + p;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -820,6 +833,314 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Wide models (16 < max(du, dv) <= 128, the d = 100 Gaussian-process toy of the reference's
+// experiments/bashes/toy_gibbs.sh): the affine drift is a (slots x D) x (D x D) product, so it runs on
+// the matrix cores.  v_mfma_f32_16x16x4_f32 accumulates as an ascending fmaf chain, bit for bit
+// (tools/mfmatest.hip), which is exactly the c-ordered chain of drift_row / the oracle.
+//
+// One workgroup = 32 destination slots x 32 rows of the drift; the grid spans (slot tiles x row
+// tiles), every workgroup of a slot tile repeating that tile's (cheap) searches and ancestor gather.
+// Rows < du become new particle coordinates (Euler-Maruyama + pin), rows >= du become per-row
+// log-density terms lpw[r'][m]; k_lgw_lse adds those in row order (the reference's sum) and
+// publishes the logsumexp tile partials.  Per step: norm -> cdf -> k_lgw_prop -> k_lgw_lse.
+// ------------------------------------------------------------------------------------------
+constexpr int kWideTile = 32;
+typedef float mfma_f4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(kBlock) k_lgw_init(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float xch[2][4];
+    const int p0 = blockIdx.x * kBlock;
+    // gibbs.py:140-144 (explicit_final=False): every particle starts at us_star[0], weights 1/N
+    for (int e = threadIdx.x; e < kBlock * d.du; e += kBlock) {
+        const int p = p0 + e / d.du, r = e % d.du;
+        if (p < d.N) {
+            const float v = d.us_star[r];
+            d.u0[(size_t)p * d.du + r] = v;
+            if (d.uss) d.uss[(size_t)p * d.du + r] = v;
+        }
+    }
+    const int p = p0 + threadIdx.x;
+    float lv[1] = {-__builtin_inff()};
+    if (p < d.N) {
+        d.lw[p] = d.lw_init;
+        lv[0] = d.lw_init;
+    }
+    float m, sx;
+    block_lse_partial<1>(lv, xch[0], xch[1], m, sx);
+    if (threadIdx.x == 0) {
+        d.bmax[blockIdx.x] = m;
+        d.bsumexp[blockIdx.x] = sx;
+    }
+}
+
+// lw[m] = lp_0 + lp_1 + ... in row order (the reference's sum over the observation coordinates)
+__device__ __forceinline__ float lgw_row_sum(const LgDev& d, int m) {
+    const float* __restrict__ p = d.lpw + m;
+    const size_t N = d.N;
+    float a = p[0];
+    int r = 1;
+    for (; r + 8 <= d.dv; r += 8) {   // eight loads in flight, added in order
+        const float x0 = p[(size_t)r * N], x1 = p[(size_t)(r + 1) * N], x2 = p[(size_t)(r + 2) * N],
+                    x3 = p[(size_t)(r + 3) * N], x4 = p[(size_t)(r + 4) * N], x5 = p[(size_t)(r + 5) * N],
+                    x6 = p[(size_t)(r + 6) * N], x7 = p[(size_t)(r + 7) * N];
+        a = a + x0; a = a + x1; a = a + x2; a = a + x3; a = a + x4; a = a + x5; a = a + x6; a = a + x7;
+    }
+    for (; r < d.dv; ++r) a = a + p[(size_t)r * N];
+    return a;
+}
+
+// log-weights from the per-row terms, then the logsumexp tile partials (N > 256, and once after the
+// last step for the final-mode kernels)
+__global__ void __launch_bounds__(kBlock) k_lgw_lse(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float xch[2][4];
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    float lv[1] = {-__builtin_inff()};
+    if (m < d.N) {
+        lv[0] = lgw_row_sum(d, m);
+        d.lw[m] = lv[0];
+    }
+    float mx, sx;
+    block_lse_partial<1>(lv, xch[0], xch[1], mx, sx);
+    if (threadIdx.x == 0) {
+        d.bmax[blockIdx.x] = mx;
+        d.bsumexp[blockIdx.x] = sx;
+    }
+}
+
+// ancestors of one step, N > 256: the search half of k_lg_prop1 (J, rotation, kill test, Cat(w) redraw, pin)
+__global__ void __launch_bounds__(kBlock) k_lgw_anc(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float heapW[kHeapSizeW], heapJ[kHeapSizeJ], win[kBlock];
+    const int N = d.N, t = threadIdx.x;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5];
+    const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
+    const int m = blockIdx.x * kBlock + t;
+    const bool live = m < N;
+    const float lastJ = d.cdfJ[N - 1];
+    const float last = d.cdf[N - 1];
+    const float w_max = d.scal[1];
+    constexpr int kPerThread = kHeapSizeW / kBlock;
+    const int nodesW = 1 << d.lh_w, nodesJ = 1 << d.lh_j;
+    float hw[kPerThread];
+#pragma unroll
+    for (int h = 0; h < kPerThread; ++h) {
+        const int node = t + h * kBlock;
+        hw[h] = (node >= 1 && node < nodesW) ? d.hpW[node] : 0.0f;
+    }
+    const float hj = (t >= 1 && t < nodesJ) ? d.hpJ[t] : 0.0f;
+    const float u3 = uniform_at(c0, c1, 1, 0);
+#pragma unroll
+    for (int h = 0; h < kPerThread; ++h) heapW[t + h * kBlock] = hw[h];
+    heapJ[t] = hj;
+    __syncthreads();
+    const int J = bisect_uniform(d.cdfJ, N, d.levels, d.lh_j, heapJ, win, lastJ * (1.0f - u3));   // resamplings.py:84
+    int shift = (j_ref - J) % N;                                                                   // :85
+    if (shift < 0) shift += N;
+    int src = m - shift;
+    if (src < 0) src += N;
+    if (!live) src = 0;
+    const float ws = d.w[src];
+    const float u1 = uniform_at(a0, a1, (uint64_t)N, (uint64_t)src);
+    const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)src);
+    const float qK = last * (1.0f - u2);                                                           // :73-74
+    int lo, hi;
+    bisect_lds_levels(N, d.lh_w, heapW, qK, lo, hi);
+    const bool killed = live && (u1 * w_max >= ws);                                                // :71
+#pragma unroll 1
+    for (int rem = d.levels - d.lh_w; rem > 0; rem -= 3) bisect_round3(d.cdf, lo, hi, qK, killed);
+    if (live) {
+        const int a = m == j_ref ? i_ref : (killed ? hi : src);                                    // :86
+        d.anc[m] = a;
+        if (d.As) d.As[(size_t)s * N + m] = a;
+    }
+}
+
+// N <= 256: the whole ensemble is one logsumexp tile and one workgroup, so everything between two
+// drift products needs no grid-wide step at all -- log-weights (row sums), normalisation, both
+// CDFs, J, the kill tests and the Cat(w) redraws run here back to back, the CDFs never leave LDS.
+// Same arithmetic, call for call, as k_lgw_lse -> k_lg_norm<1,0> -> k_lg_cdf<1,0> -> k_lgw_anc with one tile.
+__global__ void __launch_bounds__(kBlock) k_lgw_pre(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float xch[6][4];
+    __shared__ float part[2];
+    __shared__ float wS[kBlock], cW[kBlock], cJ[kBlock];
+    const int N = d.N, t = threadIdx.x;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5];
+    const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
+    const bool live = t < N;
+    // log-weights: step 0 has them from k_lgw_init, later steps sum the rows the drift kernel left
+    float l = 0.0f;
+    if (live) {
+        l = s == 0 ? d.lw[t] : lgw_row_sum(d, t);
+        if (s) d.lw[t] = l;
+    }
+    const float u3 = uniform_at(c0, c1, 1, 0);
+    // normalise (csmc.py:146): the tile partial, then the two-level combine over this one tile
+    float lv[1] = {live ? l : -__builtin_inff()};
+    float mx, sx;
+    block_lse_partial<1>(lv, xch[0], xch[1], mx, sx);
+    if (t == 0) {
+        part[0] = mx;
+        part[1] = sx;
+    }
+    __syncthreads();
+    float lse, Mraw;
+    lse_from_partials(part, part + 1, 1, xch[2], xch[3], lse, Mraw);
+    const float w_max = fbsmi_expf(Mraw - lse);
+    float w = 0.0f, xj = 0.0f;
+    if (live) {
+        const float ln = l - lse;
+        w = fbsmi_expf(ln);
+        d.w[t] = w;
+        d.lwn[t] = ln;
+        if (d.lwss) d.lwss[(size_t)s * N + t] = ln;
+        xj = t == i_ref ? 0.0f : jprob_at(w, w_max, N);
+    }
+    wS[t] = w;
+    // totals of w and of J_prob without i*; J_prob[i*] = max(1 - sum, 0) (resamplings.py:80-82)
+    float s2[2] = {w, xj}, t2[2];
+    TreePath p2[2];
+    block_upsweep_n<2>(s2, p2, xch[4], t2);
+    const float Ji = fmaxf(1.0f - t2[1], 0.0f);
+    const float xo = live ? (t == i_ref ? Ji : xj) : 0.0f;
+    float s1[1] = {xo}, t1[1];
+    TreePath p1[1];
+    __syncthreads();
+    block_upsweep_n<1>(s1, p1, xch[0], t1);
+    // canonical cumsums of the single tile: (P, E) = (0, total)
+    {
+        float P = 0.0f, E = t2[0], c[1];
+        const float xw1[1] = {w};
+        block_descend(P, E, p2[0]);
+        chunk_scan<1>(xw1, P, E, c);
+        cW[t] = c[0];
+        P = 0.0f;
+        E = t1[0];
+        const float xo1[1] = {xo};
+        block_descend(P, E, p1[0]);
+        chunk_scan<1>(xo1, P, E, c);
+        cJ[t] = c[0];
+    }
+    __syncthreads();
+    // conditional killing (resamplings.py:66-86) on the LDS-resident CDFs
+    const int J = searchsorted_left(cJ, N, d.levels, cJ[N - 1] * (1.0f - u3));
+    int shift = (j_ref - J) % N;
+    if (shift < 0) shift += N;
+    if (live) {
+        int src = t - shift;
+        if (src < 0) src += N;
+        const float u1 = uniform_at(a0, a1, (uint64_t)N, (uint64_t)src);
+        int a = src;
+        if (u1 * w_max >= wS[src]) {
+            const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)src);
+            a = searchsorted_left(cW, N, d.levels, cW[N - 1] * (1.0f - u2));
+        }
+        if (t == j_ref) a = i_ref;
+        d.anc[t] = a;
+        if (d.As) d.As[(size_t)s * N + t] = a;
+    }
+}
+
+// The drift product and what hangs on it.  nrt = row tiles = ceil(D / 32); Kp = D rounded up to a multiple of
+// 4; S = LDS row stride (>= Kp, S % 32 == 2: the 16 rows x 2 columns a half-wave reads per MFMA operand
+// then fall into 32 different banks)
+__global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, int Kp, int S) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* Gs = dyn;                    // [32 rows][S]: rows 32*tr .. of G_s
+    float* Zs = dyn + kWideTile * S;    // [32 slots][S]: z = (u[ancestor], v_prev)
+    const int N = d.N, du = d.du, D = d.D;
+    const int ts = blockIdx.x / nrt, tr = blockIdx.x - ts * nrt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t t0 = kt[6], t1 = kt[7];
+    const int j_ref = d.bs[s + 1];
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    const float* __restrict__ G = d.G + (size_t)s * D * D;
+    const float* __restrict__ g = d.g + (size_t)s * D;
+    const float sd = d.sd[s], lognorm = d.lognorm[s];
+    const float sd2 = sd * sd;
+    const float* v_prev = d.vs + (size_t)s * d.dv;
+    const float* v = d.vs + (size_t)(s + 1) * d.dv;
+    const float* ustar = d.us_star + (size_t)(s + 1) * du;
+    // ---- round 0: the G tile and the ancestor rows (wave w stages rows / slots w, w+4, ..., 64 consecutive
+    //      columns per load; Kp <= 256), this thread's four noise draws in their shadow
+    constexpr int kPerThread = (kWideTile / kWaves) * 4;
+    float gq[kPerThread], zq[kPerThread];
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) {
+        const int i = wave + kWaves * (q >> 2), c = lane + 64 * (q & 3), r = kWideTile * tr + i;
+        gq[q] = (r < D && c < D) ? G[(size_t)r * D + c] : 0.0f;
+    }
+#pragma unroll
+    for (int jj = 0; jj < kWideTile / kWaves; ++jj) {
+        const int mj = kWideTile * ts + wave + kWaves * jj;
+        const int a = mj < N ? d.anc[mj] : -1;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = lane + 64 * cc;
+            float z = 0.0f;
+            if (a >= 0 && c < D) z = c < du ? up[(size_t)a * du + c] : v_prev[c - du];
+            zq[jj * 4 + cc] = z;
+        }
+    }
+    // accumulator geometry of v_mfma_f32_16x16x4_f32: wave = (row half ar, slot half ac); register v of
+    // a lane holds (row 4*(lane/16) + v, slot lane%16) of the 16 x 16 block
+    const int ar = wave >> 1, ac = wave & 1;
+    const int row0 = kWideTile * tr + 16 * ar + 4 * (lane >> 4);
+    const int jloc = 16 * ac + (lane & 15);
+    const int mo = kWideTile * ts + jloc;   // the slot this lane's outputs belong to
+    mfma_f4 acc;
+    float xi[4];
+#pragma unroll
+    for (int vv = 0; vv < 4; ++vv) {
+        const int r = row0 + vv;
+        acc[vv] = r < D ? g[r] : 0.0f;
+        xi[vv] = (r < du && mo < N) ? normal_at(t0, t1, (uint64_t)N * du, (uint64_t)mo * du + r) : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) {
+        const int i = wave + kWaves * (q >> 2), c = lane + 64 * (q & 3);
+        if (c < Kp) {
+            Gs[i * S + c] = gq[q];
+            Zs[i * S + c] = zq[q];
+        }
+    }
+    __syncthreads();
+    // ---- drift rows: acc = g_r, then acc = fma(G[r][c], z[c], acc) for c = 0 .. D-1, on the matrix cores
+    {
+        const float* ga = Gs + (16 * ar + (lane & 15)) * S + (lane >> 4);
+        const float* zb = Zs + jloc * S + (lane >> 4);
+#pragma unroll 4
+        for (int k0 = 0; k0 < Kp; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[k0], zb[k0], acc, 0, 0, 0);
+    }
+    // ---- rows < du: transition_sampler (gp_gibbs.py:120-122) + pin (csmc.py:143);
+    //      rows >= du: the terms of likelihood_logpdf (gp_gibbs.py:131-135, csmc.py:145)
+    if (mo < N) {
+        const bool pinned = mo == j_ref;
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) {
+            const int r = row0 + vv;
+            if (r < du) {
+                float x = (Zs[jloc * S + r] + acc[vv] * d.dt) + sd * xi[vv];
+                if (pinned) x = ustar[r];
+                un[(size_t)mo * du + r] = x;
+                if (d.uss) d.uss[((size_t)(s + 1) * N + mo) * du + r] = x;
+            } else if (r < D) {
+                const int rv = r - du;
+                const float cond_m = v_prev[rv] + acc[vv] * d.dt;
+                d.lpw[(size_t)rv * N + mo] = norm_logpdf(v[rv], cond_m, sd2, lognorm);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Fused particle filters for the analytic model: bootstrap_filter (fbs/samplers/smc.py:9-88) and
 // pmcmc_filter_step (smc.py:115-158) with stratified / systematic resampling
 // (fbs/samplers/resampling.py:43-59).  Same three dependency levels per step as the Gibbs sweep:
@@ -1036,7 +1357,7 @@ __global__ void k_lg_force_move(LgDev dd) {
     }
     __syncthreads();
     const int idx = s_idx;
-    for (int r = threadIdx.x; r < d.du; r += blockDim.x) d.x0n[r] = uT[(size_t)r * d.N + idx];
+    for (int r = threadIdx.x; r < d.du; r += blockDim.x) d.x0n[r] = uT[u_at(d, r, idx)];
 }
 
 // backward scanning (csmc.py:230-270): B_T ~ Cat(w_T), B_{k-1} = A_k[B_k], x_k = uss[k, B_k]
@@ -1071,7 +1392,7 @@ __global__ void k_lg_export(LgDev dd) {
     const size_t tot = (size_t)d.N * d.du;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
         const size_t p = e / d.du, r = e - p * d.du;
-        d.usT[e] = uT[r * d.N + p];
+        d.usT[e] = uT[u_at(d, (int)r, (int)p)];
     }
 }
 
@@ -1191,8 +1512,20 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     }
     const int gpath = (d.D + 63) / 64;
     k_lg_path<<<dim3(gpath, d.C), 64, 0, st>>>(d, 0);
-    LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d)));
-    for (int k = 0; k < d.T; ++k) {
+    // wide models: MFMA drift, one workgroup per (32 slots, 32 drift rows)
+    const int w_nrt = (d.D + kWideTile - 1) / kWideTile, w_Kp = (d.D + 3) / 4 * 4;
+    const int w_S = w_Kp + ((34 - w_Kp % 32) % 32);   // >= Kp, == 2 (mod 32)
+    const size_t w_lds = sizeof(float) * 2 * kWideTile * (size_t)w_S;
+    const dim3 gwide(((d.N + kWideTile - 1) / kWideTile) * w_nrt, d.C);
+    if (d.wide) k_lgw_init<<<gtile, kBlock, 0, st>>>(d);
+    else LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d)));
+    const bool one_tile = d.wide && d.N <= kBlock;   // the steps need no grid-wide stage besides the drift product
+    for (int k = 0; one_tile && k < d.T; ++k) {
+        k_lgw_pre<<<gone, kBlock, 0, st>>>(d, k);
+        k_lgw_gemm<<<gwide, kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+    }
+    if (one_tile) k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);   // log-weights + tile partial for the final-mode kernels
+    for (int k = 0; !one_tile && k < d.T; ++k) {
         if (s->debug_mask & 1) {
             ProfScope p(s, 0, st);
             LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 0><<<gtile, kBlock, 0, st>>>(d, k)));
@@ -1203,7 +1536,11 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
         }
         if (s->debug_mask & 4) {
             ProfScope p(s, 2, st);
-            if (s->items == 1 && s->dmax <= 16 && !s->generic_prop) {
+            if (d.wide) {
+                k_lgw_anc<<<gtile, kBlock, 0, st>>>(d, k);
+                k_lgw_gemm<<<gwide, kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+                k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
+            } else if (s->items == 1 && !s->generic_prop) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
             } else {
                 LG_DISPATCH(s, (k_lg_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
@@ -1291,8 +1628,13 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     if (!m->G || !m->g || !m->sd || !m->lognorm || !m->F || !m->sqQ)
         return fail(FBSMI_ERR_ARG, "lg_sweep_create: null model table");
     const int D = m->du + m->dv;
-    if (m->du > 16 || m->dv > 16)
-        return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: du, dv > 16 need the tiled-drift kernel (not built yet)");
+    const bool wide = m->du > 16 || m->dv > 16;
+    if (wide && (m->du > 128 || m->dv > 128))
+        return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: du, dv > 128 are not supported by the fused sweep");
+    if (wide && explicit_final)
+        return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: explicit_final with du, dv > 16 is not supported by the fused sweep");
+    if (wide && (explicit_final ? nparticles + 1 : nparticles) > 131072)
+        return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: du, dv > 16 with more than 131072 particles is not supported");
     if (!explicit_backward && !store_path)
         return fail(FBSMI_ERR_ARG, "lg_sweep_create: explicit_backward=0 needs store_path (As, uss)");
     fbsmi_lg_sweep* s = new (std::nothrow) fbsmi_lg_sweep();
@@ -1312,6 +1654,8 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     d.lw_init = (float)(-log((double)nparticles));
     d.G = m->G; d.g = m->g; d.sd = m->sd; d.lognorm = m->lognorm; d.F = m->F; d.sqQ = m->sqQ;
     d.levels = bisect_levels(d.N);
+    d.wide = wide ? 1 : 0;
+    d.lpw = nullptr;
     if (const char* dm = getenv("FBSMI_DEBUG_STEP_MASK")) s->debug_mask = atoi(dm);
     if (const char* gp = getenv("FBSMI_GENERIC_PROP")) s->generic_prop = atoi(gp) != 0;
     s->items = fbsmi_tile_items(d.N);  // one workgroup = one tile of the two-level logsumexp (include/fbsmi_math.h)
@@ -1353,6 +1697,11 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     rc |= dev_alloc(s, &d.cdfJ, C * N);
     rc |= dev_alloc(s, &d.bmax, C * d.nb);
     rc |= dev_alloc(s, &d.bsumexp, C * d.nb);
+    d.anc = nullptr;
+    if (wide) {
+        rc |= dev_alloc(s, &d.lpw, C * (size_t)d.dv * N);
+        rc |= dev_alloc(s, &d.anc, C * N);
+    }
     d.hpW = d.hpJ = nullptr;
     d.lh_w = d.lh_j = 0;
     if (s->items == 1) {
@@ -1388,6 +1737,15 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming) != hipSuccess) {
         fbsmi_lg_sweep_destroy(s);
         return fail(FBSMI_ERR_HIP, "lg_sweep_create: stream/event creation failed");
+    }
+    if (wide) {
+        const int Kp = (d.D + 3) / 4 * 4, S = Kp + ((34 - Kp % 32) % 32);
+        hipError_t e = hipFuncSetAttribute((const void*)k_lgw_gemm, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(float) * 2 * kWideTile * S));
+        if (e != hipSuccess) {
+            fbsmi_lg_sweep_destroy(s);
+            return fail(FBSMI_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        }
     }
     *out = s;
     return FBSMI_OK;

@@ -185,6 +185,14 @@ class LinearGaussianBridge:
         return self._t(m_) + z @ self._t(chol)
 
     # -- fused engine ----------------------------------------------------------------------------
+    def fused_sweep_supported(self, nparticles: int, explicit_final: bool = False) -> bool:
+        """What fbsmi_lg_sweep_create accepts: du, dv <= 16 at any ensemble size up to 4M particles; du, dv <= 128
+        (drift on the matrix cores) with explicit_final=False and at most 131072 particles."""
+        wide = max(self.du, self.dv) > 16
+        if not wide:
+            return True
+        return max(self.du, self.dv) <= 128 and not explicit_final and nparticles <= 131072
+
     def sweep_handle(self, nparticles: int, explicit_backward=True, explicit_final=False, store_path=None,
                      nchains: int = 1):
         store = (not explicit_backward) if store_path is None else bool(store_path)

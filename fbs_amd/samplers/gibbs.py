@@ -75,7 +75,8 @@ def gibbs_kernel(key, x0, y0, us_star, bs_star, ts, fwd_sampler, sde, unpack, np
     Returns (x0, us_star, bs_star, acc) like the reference."""
     model = _lg_model_of(fwd_sampler, transition_sampler, likelihood_logpdf)
     nsteps = (ts.shape[0] if hasattr(ts, "shape") else len(ts)) - 1
-    if model is not None and not marg_y and not kwargs and model.T == nsteps and max(model.du, model.dv) <= 16:
+    if model is not None and not marg_y and not kwargs and model.T == nsteps and \
+            model.fused_sweep_supported(nparticles, explicit_final):
         return model.gibbs_kernel(key, x0, y0, bs_star, nparticles, explicit_backward, explicit_final)
 
     key_fwd, key_csmc, key_bridge = ops.split(key, 3)                               # :126

@@ -23,6 +23,18 @@ def toy_31():
     return dict(m0=np.array([0.1, 0.2, -0.3, 1.]), cov0=cov0, y0=np.array([0.7], np.float32), du=3)
 
 
+def toy_gp(d, dv=None, seed=5):
+    """The d-dimensional Gaussian-process toy of experiments/toy/gp_gibbs.py:32-58 (Matern-1/2 covariance on
+    linspace(0, 5, d), unit observation noise); with dv != d the observation is of the first dv coordinates."""
+    dv = d if dv is None else dv
+    zs = np.linspace(0., 5., d)
+    cov = np.exp(-np.abs(zs[None, :] - zs[:, None]))
+    H = np.eye(d)[:dv]
+    joint = np.block([[cov, cov @ H.T], [H @ cov, H @ cov @ H.T + np.eye(dv)]])
+    rng = np.random.default_rng(seed)
+    return dict(m0=np.zeros(d + dv), cov0=joint, y0=rng.normal(size=dv).astype(np.float32), du=d)
+
+
 def oracle_model_from(O, bridge):
     """An oracle LGModel fed with the PRODUCT's float32 tables (parity then isolates the kernels)."""
     h = bridge.host

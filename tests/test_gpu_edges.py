@@ -67,23 +67,31 @@ def test_capacity_limits(oracle, dev):
         long.sweep_handle(4_000_000, explicit_backward=False)    # (T+1, N, du) path storage > device memory
     with pytest.raises(RuntimeError):
         br.sweep_handle(0)
-    # du > 16 needs the tiled-drift kernel: the fused engine refuses, the dispatcher falls back to the closure tier
+    # du, dv > 128 exceed the matrix-core drift kernel: the fused engine refuses, the dispatcher falls back to the
+    # closure tier; so does explicit_final=True on a wide model
     rng = np.random.default_rng(0)
-    A = rng.normal(size=(40, 40))
-    big = fbs_amd.LinearGaussianBridge(np.zeros(40), A @ A.T / 40 + np.eye(40), StationaryConstLinearSDE(-0.5, 1.0),
-                                       np.linspace(0, 1, 6), 20, device=dev)
+    A = rng.normal(size=(260, 260))
+    big = fbs_amd.LinearGaussianBridge(np.zeros(260), A @ A.T / 260 + np.eye(260), StationaryConstLinearSDE(-0.5, 1.0),
+                                       np.linspace(0, 1, 4), 130, device=dev)
     with pytest.raises(NotImplementedError):
         big.sweep_handle(64)
     from fbs_amd.samplers import gibbs_kernel
-    out = gibbs_kernel(oracle.PRNGKey(1), torch.zeros(20, device=dev), torch.zeros(20, device=dev), None,
-                       np.zeros(6, np.int32), np.linspace(0, 1, 6), big.fwd_sampler, big.sde, big.unpack, 32,
+    out = gibbs_kernel(oracle.PRNGKey(1), torch.zeros(130, device=dev), torch.zeros(130, device=dev), None,
+                       np.zeros(4, np.int32), np.linspace(0, 1, 4), big.fwd_sampler, big.sde, big.unpack, 32,
                        big.transition_sampler, big.transition_logpdf, big.likelihood_logpdf)
-    assert out[1].shape == (6, 20) and torch.isfinite(out[1]).all()
+    assert out[1].shape == (4, 130) and torch.isfinite(out[1]).all()
+    A = rng.normal(size=(40, 40))
+    mid = fbs_amd.LinearGaussianBridge(np.zeros(40), A @ A.T / 40 + np.eye(40), StationaryConstLinearSDE(-0.5, 1.0),
+                                       np.linspace(0, 1, 6), 20, device=dev)
+    with pytest.raises(NotImplementedError):
+        mid.sweep_handle(64, explicit_final=True)
+    assert not mid.fused_sweep_supported(64, explicit_final=True) and mid.fused_sweep_supported(64)
 
 
 def test_large_dimension_closures_match_oracle(oracle, dev):
-    """du = dv = 20 (the d-dimensional GP toy of gp_gibbs.py:32-58 has joint dimension 2d): closure tier,
-    bit-exact against the oracle."""
+    """du = dv = 20 (the d-dimensional GP toy of gp_gibbs.py:32-58 has joint dimension 2d): the closure tier
+    (forced here through a kwarg-free call with explicit_final, which the fused engine does not take for wide
+    models) and the fused engine, both bit-exact against the oracle."""
     import fbs_amd
     from fbs_amd.samplers import gibbs_kernel
     from fbs_amd.sdes import StationaryConstLinearSDE
@@ -100,9 +108,12 @@ def test_large_dimension_closures_match_oracle(oracle, dev):
     x0 = rng.normal(size=d).astype(np.float32)
     bs = rng.integers(0, 48, 9).astype(np.int32)
     key = oracle.PRNGKey(17)
-    got = gibbs_kernel(key, torch.from_numpy(x0).to(dev), torch.from_numpy(y0).to(dev), None, bs, ts, br.fwd_sampler,
-                       br.sde, br.unpack, 48, br.transition_sampler, br.transition_logpdf, br.likelihood_logpdf)
-    want = oracle.gibbs_kernel_lg(om, key, x0, y0, bs, 48, True, False)
-    for a, b in zip(got, want):
-        a = a.cpu().numpy()
-        assert np.array_equal(a.view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+    for ef in (False, True):        # ef=False: fused (matrix-core drift); ef=True: closure tier
+        assert br.fused_sweep_supported(48, ef) == (not ef)
+        got = gibbs_kernel(key, torch.from_numpy(x0).to(dev), torch.from_numpy(y0).to(dev), None, bs, ts, br.fwd_sampler,
+                           br.sde, br.unpack, 48, br.transition_sampler, br.transition_logpdf, br.likelihood_logpdf,
+                           explicit_final=ef)
+        want = oracle.gibbs_kernel_lg(om, key, x0, y0, bs, 48, True, ef)
+        for a, b in zip(got, want):
+            a = a.cpu().numpy()
+            assert np.array_equal(a.view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), f"explicit_final={ef}"

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import toy_2d, toy_4d, toy_31, oracle_model_from
+from helpers import toy_2d, toy_4d, toy_31, toy_gp, oracle_model_from
 
 pytestmark = pytest.mark.gpu
 
@@ -102,6 +102,56 @@ def test_fused_sweep_matches_oracle(toy, N, T, Tend, eb, ef, oracle, dev):
         _eq(_np(got[3]), want[3], "acc")
         # chain the state like the reference's driver does
         x0, bs = want[0], want[2]
+
+
+WIDE_CASES = [
+    # du, dv, N, T, eb : wide models run the drift on the matrix cores (k_lgw_prop)
+    (100, 100, 10, 12, True),     # the reference's toy_gibbs.sh configuration (d = 100), few particles
+    (100, 100, 100, 6, True),
+    (20, 20, 300, 10, True),      # more than one logsumexp tile
+    (33, 17, 77, 8, True),        # odd sizes: D = 50 is not a multiple of 4, row tiles straddle du
+    (17, 5, 40, 8, False),        # stored path + backward scanning
+    (128, 128, 33, 3, True),      # the largest supported model
+]
+
+
+@pytest.mark.parametrize("du,dv,N,T,eb", WIDE_CASES)
+def test_wide_fused_sweep_matches_oracle(du, dv, N, T, eb, oracle, dev):
+    toy = toy_gp(du, dv)
+    ts = np.linspace(0, 1.0, T + 1)
+    br = _bridge(toy, ts, dev)
+    om = oracle_model_from(oracle, br)
+    rng = np.random.default_rng(du + N)
+    x0 = rng.normal(size=du).astype(np.float32)
+    bs = rng.integers(0, N, T + 1).astype(np.int32)
+    sweep = br.sweep_handle(N, eb, False)
+    for trial, use_graph in enumerate((False, True)):
+        key = oracle.split(oracle.PRNGKey(7 + trial), 2)[1]
+        want = oracle.gibbs_kernel_lg(om, key, x0, toy["y0"], bs, N, eb, False, debug=True)
+        got = sweep.sweep(key, x0, toy["y0"], bs, use_graph=use_graph)
+        v = sweep.views()
+        _eq(_np(v["us_T"]), want[4], "final particles")
+        _eq(_np(v["lw_T"]), want[5], "final log-weights")
+        for i, what in enumerate(("x0_next", "us_star_next", "bs_star_next", "acc")):
+            _eq(_np(got[i]), want[i], what)
+        x0, bs = want[0], want[2]
+
+
+def test_wide_batched_chains_match_single_chains(oracle, dev):
+    toy = toy_gp(40)
+    T, N, C = 6, 50, 3
+    ts = np.linspace(0, 1.0, T + 1)
+    br = _bridge(toy, ts, dev)
+    rng = np.random.default_rng(1)
+    x0 = rng.normal(size=(C, 40)).astype(np.float32)
+    bs = rng.integers(0, N, (C, T + 1)).astype(np.int32)
+    keys = oracle.split(oracle.PRNGKey(3), C)
+    batch = br.sweep_handle(N, True, False, nchains=C).sweep(keys, x0, toy["y0"], bs)
+    one = br.sweep_handle(N, True, False)
+    for c in range(C):
+        got = one.sweep(keys[c], x0[c], toy["y0"], bs[c])
+        for i in range(4):
+            _eq(_np(batch[i][c]), _np(got[i]), f"chain {c} output {i}")
 
 
 @pytest.mark.parametrize("toy,N,T", [(toy_2d, 64, 30), (toy_4d, 100, 20)])
