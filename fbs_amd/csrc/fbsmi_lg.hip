@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fbsmi.h"
@@ -72,7 +73,7 @@ struct LgDev {
     float *bmax, *bsumexp, *bsumw, *bsumJ;  // [nb]
     float *hpW, *hpJ;                       // compact bisection heaps of cdf / cdfJ (one slot per thread only)
     int wide;                               // 16 < max(du, dv) <= 128: row-major particles u0/u1 [N][du], MFMA drift
-    float* lpw;                             // [dv][N] per-row log-density terms of the wide path
+    float* lpw;                             // [N][dv rounded up to 4] per-row log-density terms of the wide path
     int32_t* anc;                           // [N] ancestors of the current step (wide path)
     int lh_w, lh_j;                         // their depths
     float* scal;       // [16]: 0 lse, 1 w_max
@@ -136,7 +137,7 @@ __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
     d.bsumw += nb * c;
     d.bsumJ += nb * c;
     if (d.lpw) {
-        d.lpw += dv * N * c;
+        d.lpw += (size_t)((d.dv + 3) & ~3) * N * c;
         d.anc += N * c;
     }
     if (d.hpW) {
@@ -838,11 +839,12 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
 // the matrix cores.  v_mfma_f32_16x16x4_f32 accumulates as an ascending fmaf chain, bit for bit
 // (tools/mfmatest.hip), which is exactly the c-ordered chain of drift_row / the oracle.
 //
-// One workgroup = 32 destination slots x 32 rows of the drift; the grid spans (slot tiles x row
-// tiles), every workgroup of a slot tile repeating that tile's (cheap) searches and ancestor gather.
+// One workgroup of the drift kernel = 32 destination slots x 32 rows of the drift; the grid spans (slot
+// tiles x row tiles), every workgroup of a slot tile gathering that tile's ancestor rows.
 // Rows < du become new particle coordinates (Euler-Maruyama + pin), rows >= du become per-row
-// log-density terms lpw[r'][m]; k_lgw_lse adds those in row order (the reference's sum) and
-// publishes the logsumexp tile partials.  Per step: norm -> cdf -> k_lgw_prop -> k_lgw_lse.
+// log-density terms lpw[m][r']; k_lgw_lse adds those in row order (the reference's sum) and
+// publishes the logsumexp tile partials.  Per step: norm -> cdf -> k_lgw_anc -> k_lgw_gemm -> k_lgw_lse,
+// or, for ensembles of at most 256 particles (one tile, one workgroup): k_lgw_pre -> k_lgw_gemm.
 // ------------------------------------------------------------------------------------------
 constexpr int kWideTile = 32;
 typedef float mfma_f4 __attribute__((ext_vector_type(4)));
@@ -874,19 +876,26 @@ __global__ void __launch_bounds__(kBlock) k_lgw_init(LgDev dd) {
     }
 }
 
-// lw[m] = lp_0 + lp_1 + ... in row order (the reference's sum over the observation coordinates)
+// lw[m] = lp_0 + lp_1 + ... in row order (the reference's sum over the observation coordinates).
+// lpw is [N][dvp] (dvp = dv rounded up to 4): a slot's terms are at most 32 float4 loads, all issued
+// before the first add, so the chain of adds waits for memory once.
 __device__ __forceinline__ float lgw_row_sum(const LgDev& d, int m) {
-    const float* __restrict__ p = d.lpw + m;
-    const size_t N = d.N;
-    float a = p[0];
-    int r = 1;
-    for (; r + 8 <= d.dv; r += 8) {   // eight loads in flight, added in order
-        const float x0 = p[(size_t)r * N], x1 = p[(size_t)(r + 1) * N], x2 = p[(size_t)(r + 2) * N],
-                    x3 = p[(size_t)(r + 3) * N], x4 = p[(size_t)(r + 4) * N], x5 = p[(size_t)(r + 5) * N],
-                    x6 = p[(size_t)(r + 6) * N], x7 = p[(size_t)(r + 7) * N];
-        a = a + x0; a = a + x1; a = a + x2; a = a + x3; a = a + x4; a = a + x5; a = a + x6; a = a + x7;
+    const int dvp = (d.dv + 3) & ~3;
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(d.lpw + (size_t)m * dvp);
+    float4 x[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) x[q] = 4 * q < d.dv ? p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float a = x[0].x;
+    if (1 < d.dv) a = a + x[0].y;
+    if (2 < d.dv) a = a + x[0].z;
+    if (3 < d.dv) a = a + x[0].w;
+#pragma unroll
+    for (int q = 1; q < 32; ++q) {
+        if (4 * q < d.dv) a = a + x[q].x;
+        if (4 * q + 1 < d.dv) a = a + x[q].y;
+        if (4 * q + 2 < d.dv) a = a + x[q].z;
+        if (4 * q + 3 < d.dv) a = a + x[q].w;
     }
-    for (; r < d.dv; ++r) a = a + p[(size_t)r * N];
     return a;
 }
 
@@ -972,12 +981,14 @@ __global__ void __launch_bounds__(kBlock) k_lgw_pre(LgDev dd, int s) {
     const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5];
     const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
     const bool live = t < N;
+    FBSMI_STAMP(25)
     // log-weights: step 0 has them from k_lgw_init, later steps sum the rows the drift kernel left
     float l = 0.0f;
     if (live) {
         l = s == 0 ? d.lw[t] : lgw_row_sum(d, t);
         if (s) d.lw[t] = l;
     }
+    FBSMI_STAMP(26)
     const float u3 = uniform_at(c0, c1, 1, 0);
     // normalise (csmc.py:146): the tile partial, then the two-level combine over this one tile
     float lv[1] = {live ? l : -__builtin_inff()};
@@ -990,6 +1001,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_pre(LgDev dd, int s) {
     __syncthreads();
     float lse, Mraw;
     lse_from_partials(part, part + 1, 1, xch[2], xch[3], lse, Mraw);
+    FBSMI_STAMP(27)
     const float w_max = fbsmi_expf(Mraw - lse);
     float w = 0.0f, xj = 0.0f;
     if (live) {
@@ -1026,6 +1038,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_pre(LgDev dd, int s) {
         cJ[t] = c[0];
     }
     __syncthreads();
+    FBSMI_STAMP(28)
     // conditional killing (resamplings.py:66-86) on the LDS-resident CDFs
     const int J = searchsorted_left(cJ, N, d.levels, cJ[N - 1] * (1.0f - u3));
     int shift = (j_ref - J) % N;
@@ -1043,6 +1056,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_pre(LgDev dd, int s) {
         d.anc[t] = a;
         if (d.As) d.As[(size_t)s * N + t] = a;
     }
+    FBSMI_STAMP(29)
 }
 
 // The drift product and what hangs on it.  nrt = row tiles = ceil(D / 32); Kp = D rounded up to a multiple of
@@ -1068,25 +1082,33 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
     const float* v_prev = d.vs + (size_t)s * d.dv;
     const float* v = d.vs + (size_t)(s + 1) * d.dv;
     const float* ustar = d.us_star + (size_t)(s + 1) * du;
-    // ---- round 0: the G tile and the ancestor rows (wave w stages rows / slots w, w+4, ..., 64 consecutive
-    //      columns per load; Kp <= 256), this thread's four noise draws in their shadow
-    constexpr int kPerThread = (kWideTile / kWaves) * 4;
-    float gq[kPerThread], zq[kPerThread];
+    FBSMI_STAMP(20)
+    // ---- round 0.  Wave w stages rows / slots w, w+4, ... of the two tiles.  The ancestors are asked for
+    //      first, the G tile next; the four noise draws of this thread run while both are in flight; the
+    //      ancestor rows (the only dependent loads) go out as soon as the ancestors are here.
+    constexpr int kRows = kWideTile / kWaves;   // 8 rows / slots per wave
+    int an[kRows];
 #pragma unroll
-    for (int q = 0; q < kPerThread; ++q) {
-        const int i = wave + kWaves * (q >> 2), c = lane + 64 * (q & 3), r = kWideTile * tr + i;
-        gq[q] = (r < D && c < D) ? G[(size_t)r * D + c] : 0.0f;
-    }
-#pragma unroll
-    for (int jj = 0; jj < kWideTile / kWaves; ++jj) {
+    for (int jj = 0; jj < kRows; ++jj) {
         const int mj = kWideTile * ts + wave + kWaves * jj;
-        const int a = mj < N ? d.anc[mj] : -1;
+        an[jj] = mj < N ? d.anc[mj] : -1;
+    }
+    const bool vec4 = (D & 3) == 0 && (du & 3) == 0;   // rows are whole float4s: one load per lane and row
+    float gq[kRows * 4], zq[kRows * 4];
+    if (vec4) {
+        const int c = 4 * lane;
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int c = lane + 64 * cc;
-            float z = 0.0f;
-            if (a >= 0 && c < D) z = c < du ? up[(size_t)a * du + c] : v_prev[c - du];
-            zq[jj * 4 + cc] = z;
+        for (int jj = 0; jj < kRows; ++jj) {
+            const int r = kWideTile * tr + wave + kWaves * jj;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < D && c < D) x = *reinterpret_cast<const float4*>(G + (size_t)r * D + c);
+            gq[jj * 4 + 0] = x.x; gq[jj * 4 + 1] = x.y; gq[jj * 4 + 2] = x.z; gq[jj * 4 + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kRows * 4; ++q) {
+            const int r = kWideTile * tr + wave + kWaves * (q >> 2), c = lane + 64 * (q & 3);
+            gq[q] = (r < D && c < D) ? G[(size_t)r * D + c] : 0.0f;
         }
     }
     // accumulator geometry of v_mfma_f32_16x16x4_f32: wave = (row half ar, slot half ac); register v of
@@ -1103,15 +1125,38 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
         acc[vv] = r < D ? g[r] : 0.0f;
         xi[vv] = (r < du && mo < N) ? normal_at(t0, t1, (uint64_t)N * du, (uint64_t)mo * du + r) : 0.0f;
     }
+    if (vec4) {
+        const int c = 4 * lane;
 #pragma unroll
-    for (int q = 0; q < kPerThread; ++q) {
-        const int i = wave + kWaves * (q >> 2), c = lane + 64 * (q & 3);
+        for (int jj = 0; jj < kRows; ++jj) {
+            const int a = an[jj];
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a >= 0 && c < D)
+                x = c < du ? *reinterpret_cast<const float4*>(up + (size_t)a * du + c)
+                           : *reinterpret_cast<const float4*>(v_prev + (c - du));
+            zq[jj * 4 + 0] = x.x; zq[jj * 4 + 1] = x.y; zq[jj * 4 + 2] = x.z; zq[jj * 4 + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kRows * 4; ++q) {
+            const int a = an[q >> 2], c = lane + 64 * (q & 3);
+            float z = 0.0f;
+            if (a >= 0 && c < D) z = c < du ? up[(size_t)a * du + c] : v_prev[c - du];
+            zq[q] = z;
+        }
+    }
+    FBSMI_STAMP(21)
+#pragma unroll
+    for (int q = 0; q < kRows * 4; ++q) {
+        const int i = wave + kWaves * (q >> 2);
+        const int c = vec4 ? 4 * lane + (q & 3) : lane + 64 * (q & 3);
         if (c < Kp) {
             Gs[i * S + c] = gq[q];
             Zs[i * S + c] = zq[q];
         }
     }
     __syncthreads();
+    FBSMI_STAMP(22)
     // ---- drift rows: acc = g_r, then acc = fma(G[r][c], z[c], acc) for c = 0 .. D-1, on the matrix cores
     {
         const float* ga = Gs + (16 * ar + (lane & 15)) * S + (lane >> 4);
@@ -1119,6 +1164,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
 #pragma unroll 4
         for (int k0 = 0; k0 < Kp; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[k0], zb[k0], acc, 0, 0, 0);
     }
+    FBSMI_STAMP(23)
     // ---- rows < du: transition_sampler (gp_gibbs.py:120-122) + pin (csmc.py:143);
     //      rows >= du: the terms of likelihood_logpdf (gp_gibbs.py:131-135, csmc.py:145)
     if (mo < N) {
@@ -1134,10 +1180,11 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
             } else if (r < D) {
                 const int rv = r - du;
                 const float cond_m = v_prev[rv] + acc[vv] * d.dt;
-                d.lpw[(size_t)rv * N + mo] = norm_logpdf(v[rv], cond_m, sd2, lognorm);
+                d.lpw[(size_t)mo * ((d.dv + 3) & ~3) + rv] = norm_logpdf(v[rv], cond_m, sd2, lognorm);
             }
         }
     }
+    FBSMI_STAMP(24)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1432,6 +1479,8 @@ struct fbsmi_lg_sweep {
     LgDev d{};
     int items = 1, dmax = 2;
     std::vector<void*> allocs;
+    std::vector<std::pair<void**, size_t>> slab_reqs;   // (pointer slot, offset) until slab_commit
+    size_t slab_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipGraphExec_t graph_single = nullptr;  // one sweep, no chain bookkeeping
@@ -1453,6 +1502,28 @@ int dev_alloc(fbsmi_lg_sweep* s, T** p, size_t count) {
     FBSMI_HIP_TRY(hipMemset(q, 0, sizeof(T) * (count ? count : 1)));
     s->allocs.push_back(q);
     *p = (T*)q;
+    return 0;
+}
+
+// The buffers of a handle are carved from ONE allocation: the step kernels touch ~20 of them per
+// launch, and as separate hipMallocs each sits in pages of its own -- a first-touch translation miss
+// per buffer per kernel, on the critical path of kernels that run for a few microseconds.
+template <typename T>
+int slab_request(fbsmi_lg_sweep* s, T** p, size_t count) {
+    const size_t bytes = (sizeof(T) * (count ? count : 1) + 255) & ~(size_t)255;
+    s->slab_reqs.push_back({(void**)p, s->slab_bytes});
+    s->slab_bytes += bytes;
+    *p = nullptr;
+    return 0;
+}
+
+int slab_commit(fbsmi_lg_sweep* s) {
+    void* q = nullptr;
+    FBSMI_HIP_TRY(hipMalloc(&q, s->slab_bytes ? s->slab_bytes : 256));
+    s->allocs.push_back(q);
+    FBSMI_HIP_TRY(hipMemset(q, 0, s->slab_bytes ? s->slab_bytes : 256));
+    for (auto& r : s->slab_reqs) *r.first = (char*)q + r.second;
+    s->slab_reqs.clear();
     return 0;
 }
 
@@ -1676,31 +1747,31 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     }
     const size_t N = d.N, T = d.T, C = nchains;
     int rc = 0;
-    rc |= dev_alloc(s, &d.key, 2);
-    rc |= dev_alloc(s, &d.keys, 2 * C);
-    rc |= dev_alloc(s, &d.x0, C * d.du);
-    rc |= dev_alloc(s, &d.y0, d.dv);
-    rc |= dev_alloc(s, &d.bs, C * (T + 1));
-    rc |= dev_alloc(s, &d.keytab, C * 8 * T);
-    rc |= dev_alloc(s, &d.misc, C * 16);
-    rc |= dev_alloc(s, &d.xi1, C * T * D);
-    rc |= dev_alloc(s, &d.xi2, C * T * D);
-    rc |= dev_alloc(s, &d.path, 1);
-    rc |= dev_alloc(s, &d.us_star, C * (T + 1) * d.du);
-    rc |= dev_alloc(s, &d.vs, C * (T + 1) * d.dv);
-    rc |= dev_alloc(s, &d.u0, C * N * d.du);
-    rc |= dev_alloc(s, &d.u1, C * N * d.du);
-    rc |= dev_alloc(s, &d.lw, C * N);
-    rc |= dev_alloc(s, &d.lwn, C * N);
-    rc |= dev_alloc(s, &d.w, C * N);
-    rc |= dev_alloc(s, &d.cdf, C * N);
-    rc |= dev_alloc(s, &d.cdfJ, C * N);
-    rc |= dev_alloc(s, &d.bmax, C * d.nb);
-    rc |= dev_alloc(s, &d.bsumexp, C * d.nb);
+    rc |= slab_request(s, &d.key, 2);
+    rc |= slab_request(s, &d.keys, 2 * C);
+    rc |= slab_request(s, &d.x0, C * d.du);
+    rc |= slab_request(s, &d.y0, d.dv);
+    rc |= slab_request(s, &d.bs, C * (T + 1));
+    rc |= slab_request(s, &d.keytab, C * 8 * T);
+    rc |= slab_request(s, &d.misc, C * 16);
+    rc |= slab_request(s, &d.xi1, C * T * D);
+    rc |= slab_request(s, &d.xi2, C * T * D);
+    rc |= slab_request(s, &d.path, 1);
+    rc |= slab_request(s, &d.us_star, C * (T + 1) * d.du);
+    rc |= slab_request(s, &d.vs, C * (T + 1) * d.dv);
+    rc |= slab_request(s, &d.u0, C * N * d.du);
+    rc |= slab_request(s, &d.u1, C * N * d.du);
+    rc |= slab_request(s, &d.lw, C * N);
+    rc |= slab_request(s, &d.lwn, C * N);
+    rc |= slab_request(s, &d.w, C * N);
+    rc |= slab_request(s, &d.cdf, C * N);
+    rc |= slab_request(s, &d.cdfJ, C * N);
+    rc |= slab_request(s, &d.bmax, C * d.nb);
+    rc |= slab_request(s, &d.bsumexp, C * d.nb);
     d.anc = nullptr;
     if (wide) {
-        rc |= dev_alloc(s, &d.lpw, C * (size_t)d.dv * N);
-        rc |= dev_alloc(s, &d.anc, C * N);
+        rc |= slab_request(s, &d.lpw, C * (size_t)((d.dv + 3) & ~3) * N);
+        rc |= slab_request(s, &d.anc, C * N);
     }
     d.hpW = d.hpJ = nullptr;
     d.lh_w = d.lh_j = 0;
@@ -1709,25 +1780,26 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         while ((2ll << fl) <= (long long)d.N) ++fl;   // floor(log2 N)
         d.lh_w = fl < kHeapLevelsW ? fl : kHeapLevelsW;
         d.lh_j = fl < kHeapLevelsJ ? fl : kHeapLevelsJ;
-        rc |= dev_alloc(s, &d.hpW, C * (size_t)kHeapSizeW);
-        rc |= dev_alloc(s, &d.hpJ, C * (size_t)kHeapSizeJ);
+        rc |= slab_request(s, &d.hpW, C * (size_t)kHeapSizeW);
+        rc |= slab_request(s, &d.hpJ, C * (size_t)kHeapSizeJ);
     }
-    rc |= dev_alloc(s, &d.bsumw, C * d.nb);
-    rc |= dev_alloc(s, &d.bsumJ, C * d.nb);
-    rc |= dev_alloc(s, &d.scal, C * 16);
-    rc |= dev_alloc(s, &d.usT, C * N * d.du);
-    rc |= dev_alloc(s, &d.x0n, C * d.du);
-    rc |= dev_alloc(s, &d.usn, C * (T + 1) * d.du);
-    rc |= dev_alloc(s, &d.bsn, C * (T + 1));
-    rc |= dev_alloc(s, &d.acc, C * (T + 1));
-    rc |= dev_alloc(s, &d.x0s_slot, 1);
-    rc |= dev_alloc(s, &d.counter, 1);
-    rc |= dev_alloc(s, &d.dbg, 64);
+    rc |= slab_request(s, &d.bsumw, C * d.nb);
+    rc |= slab_request(s, &d.bsumJ, C * d.nb);
+    rc |= slab_request(s, &d.scal, C * 16);
+    rc |= slab_request(s, &d.usT, C * N * d.du);
+    rc |= slab_request(s, &d.x0n, C * d.du);
+    rc |= slab_request(s, &d.usn, C * (T + 1) * d.du);
+    rc |= slab_request(s, &d.bsn, C * (T + 1));
+    rc |= slab_request(s, &d.acc, C * (T + 1));
+    rc |= slab_request(s, &d.x0s_slot, 1);
+    rc |= slab_request(s, &d.counter, 1);
+    rc |= slab_request(s, &d.dbg, 64);
     if (store_path) {
-        rc |= dev_alloc(s, &d.As, C * T * N);
-        rc |= dev_alloc(s, &d.uss, C * (T + 1) * N * d.du);
-        rc |= dev_alloc(s, &d.lwss, C * (T + 1) * N);
+        rc |= slab_request(s, &d.As, C * T * N);
+        rc |= slab_request(s, &d.uss, C * (T + 1) * N * d.du);
+        rc |= slab_request(s, &d.lwss, C * (T + 1) * N);
     }
+    rc |= slab_commit(s);
     if (rc) {
         fbsmi_lg_sweep_destroy(s);
         return FBSMI_ERR_HIP;
