@@ -55,6 +55,41 @@ def max_over_ranks(dt, dist, dev):
     return float(tt.item())
 
 
+def gp100_leg(dev):
+    """The reference's own toy experiment (experiments/bashes/toy_gibbs.sh + tabulators/tabulate_toy.py:
+    gp_gibbs.py --d=100 --nparticles=100 --explicit_backward, 4 chains, T = 200): joint dimension D = 200, so
+    the affine drift is a (slots x 200) x (200 x 200) product per step and runs on the f32 matrix cores
+    (k_lgw_gemm).  Outside the timed region of the headline metric; reported beside it."""
+    import fbs_amd
+    from fbs_amd.sdes import StationaryConstLinearSDE
+    d, T, C = 100, 200, 4
+    zs = np.linspace(0., 5., d)
+    cov = np.exp(-np.abs(zs[None, :] - zs[:, None]))                               # gp_gibbs.py:39-40
+    joint = np.block([[cov, cov], [cov, cov + np.eye(d)]])                          # :55-57
+    ts = np.linspace(0., 1., T + 1)
+    br = fbs_amd.LinearGaussianBridge(np.zeros(2 * d), joint, StationaryConstLinearSDE(a=-0.5, b=1.), ts, d, device=dev)
+    y0 = np.random.default_rng(0).normal(size=d).astype(np.float32)
+    out = []
+    for N, nrep in ((100, 20), (10000, 5)):
+        sw = br.sweep_handle(N, True, False, nchains=C)
+        k, x, b, _ = sw.chain(fbs_amd.PRNGKey(1), np.zeros((C, d), np.float32), y0, np.zeros((C, T + 1), np.int32), 2,
+                              keep=False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        sw.chain(k, x, y0, b, nrep, keep=False)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / nrep
+        tf = 2.0 * N * (2 * d) ** 2 * T * C / dt / 1e12
+        out.append({"nparticles": N, "d": d, "nsteps": T, "nchains": C, "ms_per_sweep": dt * 1e3,
+                    "value": float(N) * T * C / dt, "unit": "particle-steps/s",
+                    "drift_TFLOPs": tf, "frac_of_f32_mfma_peak": tf / 157.3})
+        del sw
+    return {"workload": "gp_gibbs.py --d=100 --explicit_backward (toy_gibbs.sh), 4 chains; nparticles=100 is the paper's "
+                        "table (tabulate_toy.py:16), 10000 shows the drift kernel loaded", "runs": out,
+            "note": "f32 MFMA (exact fmaf chain) dense peak 157.3 TFLOP/s; at nparticles=100 a step is two launches "
+                    "and latency-bound"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +101,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sweeps", type=int, default=2)
     ap.add_argument("--no-single-chain", action="store_true")
+    ap.add_argument("--no-gp100", action="store_true", help="skip the d = 100 Gaussian-process toy leg (`gp100`)")
     ap.add_argument("--batch-scan", type=str, default="16,32",
                     help="extra chain-batch sizes timed (untimed region) and reported in `batch_scan`; '' to skip")
     args = ap.parse_args()
@@ -182,6 +218,9 @@ def main():
                 scan.append({"nchains": cb, "value": float(N) * T * cb / bdt, "ms_per_sweep": bdt * 1e3,
                              "whole_sweep_GBps": bpp["step"] * float(N) * T * cb / bdt / 1e9})
                 del swb
+        gp100 = None
+        if world == 1 and not args.no_gp100 and not args.no_single_chain:
+            gp100 = gp100_leg(dev)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             import oracle as O
@@ -210,7 +249,7 @@ def main():
                           "(reference driver default nchains=4, vmapped)",
                           "nparticles": N, "nsteps": T, "nchains": C, "du": br.du, "dv": br.dv,
                           "parallelism": f"{world} GPU(s) x {C} independent chain(s) each, no collective"},
-               "roofline": roofline, "cpu_baseline": cpu, "single_chain": single, "batch_scan": scan,
+               "roofline": roofline, "cpu_baseline": cpu, "single_chain": single, "batch_scan": scan, "gp100": gp100,
                "x0_mean_of_timed_sweeps": float(x0s.float().mean().item())}
     if dist is not None:
         dist.barrier()

@@ -844,7 +844,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
 // Rows < du become new particle coordinates (Euler-Maruyama + pin), rows >= du become per-row
 // log-density terms lpw[m][r']; k_lgw_lse adds those in row order (the reference's sum) and
 // publishes the logsumexp tile partials.  Per step: norm -> cdf -> k_lgw_anc -> k_lgw_gemm -> k_lgw_lse,
-// or, for ensembles of at most 256 particles (one tile, one workgroup): k_lgw_pre -> k_lgw_gemm.
+// or, for ensembles of at most 256 particles (one tile), a single launch: k_lgw_gemm<true>.
 // ------------------------------------------------------------------------------------------
 constexpr int kWideTile = 32;
 typedef float mfma_f4 __attribute__((ext_vector_type(4)));
@@ -879,24 +879,36 @@ __global__ void __launch_bounds__(kBlock) k_lgw_init(LgDev dd) {
 // lw[m] = lp_0 + lp_1 + ... in row order (the reference's sum over the observation coordinates).
 // lpw is [N][dvp] (dvp = dv rounded up to 4): a slot's terms are at most 32 float4 loads, all issued
 // before the first add, so the chain of adds waits for memory once.
-__device__ __forceinline__ float lgw_row_sum(const LgDev& d, int m) {
+struct LgwRowLoads {
+    float4 x[32];
+};
+
+__device__ __forceinline__ void lgw_row_issue(const LgDev& d, int m, LgwRowLoads& L) {
     const int dvp = (d.dv + 3) & ~3;
     const float4* __restrict__ p = reinterpret_cast<const float4*>(d.lpw + (size_t)m * dvp);
-    float4 x[32];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) x[q] = 4 * q < d.dv ? p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float a = x[0].x;
-    if (1 < d.dv) a = a + x[0].y;
-    if (2 < d.dv) a = a + x[0].z;
-    if (3 < d.dv) a = a + x[0].w;
+    for (int q = 0; q < 32; ++q) L.x[q] = 4 * q < d.dv ? p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ float lgw_row_add(const LgDev& d, const LgwRowLoads& L) {
+    float a = L.x[0].x;
+    if (1 < d.dv) a = a + L.x[0].y;
+    if (2 < d.dv) a = a + L.x[0].z;
+    if (3 < d.dv) a = a + L.x[0].w;
 #pragma unroll
     for (int q = 1; q < 32; ++q) {
-        if (4 * q < d.dv) a = a + x[q].x;
-        if (4 * q + 1 < d.dv) a = a + x[q].y;
-        if (4 * q + 2 < d.dv) a = a + x[q].z;
-        if (4 * q + 3 < d.dv) a = a + x[q].w;
+        if (4 * q < d.dv) a = a + L.x[q].x;
+        if (4 * q + 1 < d.dv) a = a + L.x[q].y;
+        if (4 * q + 2 < d.dv) a = a + L.x[q].z;
+        if (4 * q + 3 < d.dv) a = a + L.x[q].w;
     }
     return a;
+}
+
+__device__ __forceinline__ float lgw_row_sum(const LgDev& d, int m) {
+    LgwRowLoads L;
+    lgw_row_issue(d, m, L);
+    return lgw_row_add(d, L);
 }
 
 // log-weights from the per-row terms, then the logsumexp tile partials (N > 256, and once after the
@@ -967,15 +979,24 @@ __global__ void __launch_bounds__(kBlock) k_lgw_anc(LgDev dd, int s) {
     }
 }
 
-// N <= 256: the whole ensemble is one logsumexp tile and one workgroup, so everything between two
-// drift products needs no grid-wide step at all -- log-weights (row sums), normalisation, both
-// CDFs, J, the kill tests and the Cat(w) redraws run here back to back, the CDFs never leave LDS.
-// Same arithmetic, call for call, as k_lgw_lse -> k_lg_norm<1,0> -> k_lg_cdf<1,0> -> k_lgw_anc with one tile.
-__global__ void __launch_bounds__(kBlock) k_lgw_pre(LgDev dd, int s) {
-    const LgDev d = chain_view(dd, blockIdx.y);
-    __shared__ float xch[6][4];
-    __shared__ float part[2];
-    __shared__ float wS[kBlock], cW[kBlock], cJ[kBlock];
+// N <= 256: the whole ensemble is one logsumexp tile and fits one workgroup, so nothing between two drift
+// products needs a grid-wide step: log-weights (row sums), normalisation, both CDFs, J, the kill
+// tests and the Cat(w) redraws run back to back inside every workgroup of the drift kernel (the
+// redundancy is a few microseconds of a CU that would otherwise wait for a launch), the CDFs never
+// leave LDS, and a step is ONE launch.  Same arithmetic, call for call, as
+// k_lgw_lse -> k_lg_norm<1,0> -> k_lg_cdf<1,0> -> k_lgw_anc with one tile.  `store`: this workgroup
+// writes the by-products (lw, w, lwn, stored paths); every workgroup gets the ancestors in ancS.
+struct LgwPreLds {
+    float xch[6][4];
+    float cW[kBlock], cJ[kBlock];
+    int ancP[kBlock];   // ancestor of SOURCE slot p (itself, or its Cat(w) redraw if killed)
+    int ancS[kBlock];   // ancestor of DESTINATION slot m
+};
+
+// `early` runs between the issue of this thread's loads and their first use (the drift kernel draws its
+// noise there).
+template <typename Early>
+__device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, LgwPreLds& L, Early early) {
     const int N = d.N, t = threadIdx.x;
     const uint32_t* kt = d.keytab + 8 * s;
     const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5];
@@ -983,87 +1004,96 @@ __global__ void __launch_bounds__(kBlock) k_lgw_pre(LgDev dd, int s) {
     const bool live = t < N;
     FBSMI_STAMP(25)
     // log-weights: step 0 has them from k_lgw_init, later steps sum the rows the drift kernel left
+    LgwRowLoads rows;
     float l = 0.0f;
     if (live) {
-        l = s == 0 ? d.lw[t] : lgw_row_sum(d, t);
-        if (s) d.lw[t] = l;
+        if (s == 0) l = d.lw[t];
+        else lgw_row_issue(d, t, rows);
+    }
+    // in the shadow of those loads: the caller's work and the three uniforms of this thread -- as a SOURCE
+    // slot p = t it owns the kill test and the redraw of p (resamplings.py:71-74), whatever the rotation
+    early();
+    const float u3 = uniform_at(c0, c1, 1, 0);
+    const float u1 = live ? uniform_at(a0, a1, (uint64_t)N, (uint64_t)t) : 0.0f;
+    const float u2 = live ? uniform_at(b0, b1, (uint64_t)N, (uint64_t)t) : 0.0f;
+    if (live && s) {
+        l = lgw_row_add(d, rows);
+        if (store) d.lw[t] = l;
     }
     FBSMI_STAMP(26)
-    const float u3 = uniform_at(c0, c1, 1, 0);
-    // normalise (csmc.py:146): the tile partial, then the two-level combine over this one tile
+    // normalise (csmc.py:146).  One tile: the two-level logsumexp combine multiplies the tile's sum by
+    // exp(0) = 1 and adds zeros, i.e. lse = log(sum) + max' exactly.
     float lv[1] = {live ? l : -__builtin_inff()};
-    float mx, sx;
-    block_lse_partial<1>(lv, xch[0], xch[1], mx, sx);
-    if (t == 0) {
-        part[0] = mx;
-        part[1] = sx;
-    }
-    __syncthreads();
-    float lse, Mraw;
-    lse_from_partials(part, part + 1, 1, xch[2], xch[3], lse, Mraw);
+    float Mraw, sx;
+    block_lse_partial<1>(lv, L.xch[0], L.xch[1], Mraw, sx);
+    const float lse = fbsmi_logf(sx) + finite_or_zero_f(Mraw);
     FBSMI_STAMP(27)
     const float w_max = fbsmi_expf(Mraw - lse);
     float w = 0.0f, xj = 0.0f;
     if (live) {
         const float ln = l - lse;
         w = fbsmi_expf(ln);
-        d.w[t] = w;
-        d.lwn[t] = ln;
-        if (d.lwss) d.lwss[(size_t)s * N + t] = ln;
+        if (store) {
+            d.w[t] = w;
+            d.lwn[t] = ln;
+            if (d.lwss) d.lwss[(size_t)s * N + t] = ln;
+        }
         xj = t == i_ref ? 0.0f : jprob_at(w, w_max, N);
     }
-    wS[t] = w;
     // totals of w and of J_prob without i*; J_prob[i*] = max(1 - sum, 0) (resamplings.py:80-82)
     float s2[2] = {w, xj}, t2[2];
     TreePath p2[2];
-    block_upsweep_n<2>(s2, p2, xch[4], t2);
+    block_upsweep_n<2>(s2, p2, L.xch[2], t2);
     const float Ji = fmaxf(1.0f - t2[1], 0.0f);
     const float xo = live ? (t == i_ref ? Ji : xj) : 0.0f;
     float s1[1] = {xo}, t1[1];
     TreePath p1[1];
-    __syncthreads();
-    block_upsweep_n<1>(s1, p1, xch[0], t1);
+    block_upsweep_n<1>(s1, p1, L.xch[4], t1);
     // canonical cumsums of the single tile: (P, E) = (0, total)
     {
         float P = 0.0f, E = t2[0], c[1];
         const float xw1[1] = {w};
         block_descend(P, E, p2[0]);
         chunk_scan<1>(xw1, P, E, c);
-        cW[t] = c[0];
+        L.cW[t] = c[0];
         P = 0.0f;
         E = t1[0];
         const float xo1[1] = {xo};
         block_descend(P, E, p1[0]);
         chunk_scan<1>(xo1, P, E, c);
-        cJ[t] = c[0];
+        L.cJ[t] = c[0];
     }
     __syncthreads();
     FBSMI_STAMP(28)
-    // conditional killing (resamplings.py:66-86) on the LDS-resident CDFs
-    const int J = searchsorted_left(cJ, N, d.levels, cJ[N - 1] * (1.0f - u3));
+    // conditional killing (resamplings.py:66-86) on the LDS-resident CDFs: J and the per-source redraws are
+    // independent searches, their LDS walks overlap
+    const int J = searchsorted_left(L.cJ, N, d.levels, L.cJ[N - 1] * (1.0f - u3));
+    int ap = t;
+    if (live && u1 * w_max >= w) ap = searchsorted_left(L.cW, N, d.levels, L.cW[N - 1] * (1.0f - u2));
+    L.ancP[t] = ap;
     int shift = (j_ref - J) % N;
     if (shift < 0) shift += N;
+    __syncthreads();
+    int a = -1;
     if (live) {
         int src = t - shift;
         if (src < 0) src += N;
-        const float u1 = uniform_at(a0, a1, (uint64_t)N, (uint64_t)src);
-        int a = src;
-        if (u1 * w_max >= wS[src]) {
-            const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)src);
-            a = searchsorted_left(cW, N, d.levels, cW[N - 1] * (1.0f - u2));
-        }
-        if (t == j_ref) a = i_ref;
-        d.anc[t] = a;
-        if (d.As) d.As[(size_t)s * N + t] = a;
+        a = t == j_ref ? i_ref : L.ancP[src];
+        if (store && d.As) d.As[(size_t)s * N + t] = a;
     }
+    L.ancS[t] = a;
+    __syncthreads();
     FBSMI_STAMP(29)
 }
 
 // The drift product and what hangs on it.  nrt = row tiles = ceil(D / 32); Kp = D rounded up to a multiple of
-// 4; S = LDS row stride (>= Kp, S % 32 == 2: the 16 rows x 2 columns a half-wave reads per MFMA operand
-// then fall into 32 different banks)
+// 16, Q = Kp / 4.  LDS tiles are [32][S] with column c stored at (c % 4) * Q + c / 4: lane group g of an
+// MFMA (which supplies column 4q + g of instruction q) then finds its columns of four consecutive
+// instructions in one aligned float4.  S % 64 == 4: the 16 lanes of a ds_read_b128 pass cover all 64 banks.
+template <bool FUSED>
 __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, int Kp, int S) {
     const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ LgwPreLds pre;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* Gs = dyn;                    // [32 rows][S]: rows 32*tr .. of G_s
     float* Zs = dyn + kWideTile * S;    // [32 slots][S]: z = (u[ancestor], v_prev)
@@ -1088,10 +1118,12 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
     //      ancestor rows (the only dependent loads) go out as soon as the ancestors are here.
     constexpr int kRows = kWideTile / kWaves;   // 8 rows / slots per wave
     int an[kRows];
+    if (!FUSED) {
 #pragma unroll
-    for (int jj = 0; jj < kRows; ++jj) {
-        const int mj = kWideTile * ts + wave + kWaves * jj;
-        an[jj] = mj < N ? d.anc[mj] : -1;
+        for (int jj = 0; jj < kRows; ++jj) {
+            const int mj = kWideTile * ts + wave + kWaves * jj;
+            an[jj] = mj < N ? d.anc[mj] : -1;
+        }
     }
     const bool vec4 = (D & 3) == 0 && (du & 3) == 0;   // rows are whole float4s: one load per lane and row
     float gq[kRows * 4], zq[kRows * 4];
@@ -1120,10 +1152,22 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
     mfma_f4 acc;
     float xi[4];
 #pragma unroll
-    for (int vv = 0; vv < 4; ++vv) {
-        const int r = row0 + vv;
-        acc[vv] = r < D ? g[r] : 0.0f;
-        xi[vv] = (r < du && mo < N) ? normal_at(t0, t1, (uint64_t)N * du, (uint64_t)mo * du + r) : 0.0f;
+    for (int vv = 0; vv < 4; ++vv) acc[vv] = row0 + vv < D ? g[row0 + vv] : 0.0f;
+    auto draw_noise = [&]() {
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) {
+            const int r = row0 + vv;
+            xi[vv] = (r < du && mo < N) ? normal_at(t0, t1, (uint64_t)N * du, (uint64_t)mo * du + r) : 0.0f;
+        }
+    };
+    if (!FUSED) draw_noise();
+    if (FUSED) {   // the G tile is on its way; now the step's ancestors, worked out by this workgroup itself
+        lgw_pre_body(d, s, blockIdx.x == 0, pre, draw_noise);
+#pragma unroll
+        for (int jj = 0; jj < kRows; ++jj) {
+            const int mj = kWideTile * ts + wave + kWaves * jj;
+            an[jj] = mj < N ? pre.ancS[mj] : -1;
+        }
     }
     if (vec4) {
         const int c = 4 * lane;
@@ -1146,23 +1190,31 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
         }
     }
     FBSMI_STAMP(21)
+    const int Q = Kp >> 2;
 #pragma unroll
     for (int q = 0; q < kRows * 4; ++q) {
         const int i = wave + kWaves * (q >> 2);
         const int c = vec4 ? 4 * lane + (q & 3) : lane + 64 * (q & 3);
         if (c < Kp) {
-            Gs[i * S + c] = gq[q];
-            Zs[i * S + c] = zq[q];
+            const int pos = i * S + (c & 3) * Q + (c >> 2);
+            Gs[pos] = gq[q];
+            Zs[pos] = zq[q];
         }
     }
     __syncthreads();
     FBSMI_STAMP(22)
     // ---- drift rows: acc = g_r, then acc = fma(G[r][c], z[c], acc) for c = 0 .. D-1, on the matrix cores
     {
-        const float* ga = Gs + (16 * ar + (lane & 15)) * S + (lane >> 4);
-        const float* zb = Zs + jloc * S + (lane >> 4);
-#pragma unroll 4
-        for (int k0 = 0; k0 < Kp; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[k0], zb[k0], acc, 0, 0, 0);
+        const float4* ga = reinterpret_cast<const float4*>(Gs + (16 * ar + (lane & 15)) * S + (lane >> 4) * Q);
+        const float4* zb = reinterpret_cast<const float4*>(Zs + jloc * S + (lane >> 4) * Q);
+#pragma unroll 2
+        for (int q4 = 0; q4 < (Q >> 2); ++q4) {
+            const float4 a = ga[q4], b = zb[q4];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+        }
     }
     FBSMI_STAMP(23)
     // ---- rows < du: transition_sampler (gp_gibbs.py:120-122) + pin (csmc.py:143);
@@ -1173,7 +1225,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
         for (int vv = 0; vv < 4; ++vv) {
             const int r = row0 + vv;
             if (r < du) {
-                float x = (Zs[jloc * S + r] + acc[vv] * d.dt) + sd * xi[vv];
+                float x = (Zs[jloc * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
                 if (pinned) x = ustar[r];
                 un[(size_t)mo * du + r] = x;
                 if (d.uss) d.uss[((size_t)(s + 1) * N + mo) * du + r] = x;
@@ -1584,17 +1636,14 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     const int gpath = (d.D + 63) / 64;
     k_lg_path<<<dim3(gpath, d.C), 64, 0, st>>>(d, 0);
     // wide models: MFMA drift, one workgroup per (32 slots, 32 drift rows)
-    const int w_nrt = (d.D + kWideTile - 1) / kWideTile, w_Kp = (d.D + 3) / 4 * 4;
-    const int w_S = w_Kp + ((34 - w_Kp % 32) % 32);   // >= Kp, == 2 (mod 32)
+    const int w_nrt = (d.D + kWideTile - 1) / kWideTile, w_Kp = (d.D + 15) / 16 * 16;
+    const int w_S = w_Kp + ((68 - w_Kp % 64) % 64);   // >= Kp, == 4 (mod 64)
     const size_t w_lds = sizeof(float) * 2 * kWideTile * (size_t)w_S;
     const dim3 gwide(((d.N + kWideTile - 1) / kWideTile) * w_nrt, d.C);
     if (d.wide) k_lgw_init<<<gtile, kBlock, 0, st>>>(d);
     else LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d)));
     const bool one_tile = d.wide && d.N <= kBlock;   // the steps need no grid-wide stage besides the drift product
-    for (int k = 0; one_tile && k < d.T; ++k) {
-        k_lgw_pre<<<gone, kBlock, 0, st>>>(d, k);
-        k_lgw_gemm<<<gwide, kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
-    }
+    for (int k = 0; one_tile && k < d.T; ++k) k_lgw_gemm<true><<<gwide, kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
     if (one_tile) k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);   // log-weights + tile partial for the final-mode kernels
     for (int k = 0; !one_tile && k < d.T; ++k) {
         if (s->debug_mask & 1) {
@@ -1609,7 +1658,7 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
             ProfScope p(s, 2, st);
             if (d.wide) {
                 k_lgw_anc<<<gtile, kBlock, 0, st>>>(d, k);
-                k_lgw_gemm<<<gwide, kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+                k_lgw_gemm<false><<<gwide, kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
                 k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
             } else if (s->items == 1 && !s->generic_prop) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
@@ -1811,9 +1860,12 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         return fail(FBSMI_ERR_HIP, "lg_sweep_create: stream/event creation failed");
     }
     if (wide) {
-        const int Kp = (d.D + 3) / 4 * 4, S = Kp + ((34 - Kp % 32) % 32);
-        hipError_t e = hipFuncSetAttribute((const void*)k_lgw_gemm, hipFuncAttributeMaxDynamicSharedMemorySize,
+        const int Kp = (d.D + 15) / 16 * 16, S = Kp + ((68 - Kp % 64) % 64);
+        hipError_t e = hipFuncSetAttribute((const void*)k_lgw_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(sizeof(float) * 2 * kWideTile * S));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)k_lgw_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(float) * 2 * kWideTile * S));
         if (e != hipSuccess) {
             fbsmi_lg_sweep_destroy(s);
             return fail(FBSMI_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));

@@ -26,10 +26,10 @@ int main(int argc, char** argv) {
     unsigned long long hh[64]; (void)hipMemcpy(hh, d, sizeof(hh), hipMemcpyDeviceToHost);
     auto rt = [&](int i) { return (double)hh[2 * i] * 10.0; };   // ns
     const char* names[32] = {};
-    names[25] = "pre in"; names[26] = "pre row sums done"; names[27] = "pre lse known"; names[28] = "pre CDFs in LDS"; names[29] = "pre out";
-    names[20] = "gemm in"; names[21] = "gemm loads landed, noise drawn"; names[22] = "gemm tiles in LDS"; names[23] = "gemm MFMA done"; names[24] = "gemm out";
-    int order[] = {25, 26, 27, 28, 29, 20, 21, 22, 23, 24};
-    double t0 = rt(25), prev = t0;
+    names[25] = "G tile + noise under way, pre in"; names[26] = "pre row sums done"; names[27] = "pre lse known"; names[28] = "pre CDFs in LDS"; names[29] = "pre out";
+    names[20] = "gemm in"; names[21] = "gemm ancestor rows landed"; names[22] = "gemm tiles in LDS"; names[23] = "gemm MFMA done"; names[24] = "gemm out";
+    int order[] = {20, 25, 26, 27, 28, 29, 21, 22, 23, 24};
+    double t0 = rt(20), prev = t0;
     for (int i : order) { printf("%-32s t=%8.0f ns  (+%6.0f)\n", names[i], rt(i) - t0, rt(i) - prev); prev = rt(i); }
     printf("(d=100, N=%d, chains=%d; the last step of a sweep)\n", N, C);
     return 0;
