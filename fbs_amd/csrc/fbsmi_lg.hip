@@ -995,7 +995,7 @@ struct LgwPreLds {
 
 // `early` runs between the issue of this thread's loads and their first use (the drift kernel draws its
 // noise there).
-template <typename Early>
+template <bool ROWS, typename Early>
 __device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, LgwPreLds& L, Early early) {
     const int N = d.N, t = threadIdx.x;
     const uint32_t* kt = d.keytab + 8 * s;
@@ -1007,7 +1007,7 @@ __device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, 
     LgwRowLoads rows;
     float l = 0.0f;
     if (live) {
-        if (s == 0) l = d.lw[t];
+        if (!ROWS || s == 0) l = d.lw[t];
         else lgw_row_issue(d, t, rows);
     }
     // in the shadow of those loads: the caller's work and the three uniforms of this thread -- as a SOURCE
@@ -1016,7 +1016,7 @@ __device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, 
     const float u3 = uniform_at(c0, c1, 1, 0);
     const float u1 = live ? uniform_at(a0, a1, (uint64_t)N, (uint64_t)t) : 0.0f;
     const float u2 = live ? uniform_at(b0, b1, (uint64_t)N, (uint64_t)t) : 0.0f;
-    if (live && s) {
+    if (ROWS && live && s) {
         l = lgw_row_add(d, rows);
         if (store) d.lw[t] = l;
     }
@@ -1162,7 +1162,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
     };
     if (!FUSED) draw_noise();
     if (FUSED) {   // the G tile is on its way; now the step's ancestors, worked out by this workgroup itself
-        lgw_pre_body(d, s, blockIdx.x == 0, pre, draw_noise);
+        lgw_pre_body<true>(d, s, blockIdx.x == 0, pre, draw_noise);
 #pragma unroll
         for (int jj = 0; jj < kRows; ++jj) {
             const int mj = kWideTile * ts + wave + kWaves * jj;
@@ -1237,6 +1237,68 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
         }
     }
     FBSMI_STAMP(24)
+}
+
+// ------------------------------------------------------------------------------------------
+// Narrow models with at most 256 particles: the ensemble is one tile and one workgroup, so a whole SMC
+// step -- normalise, both CDFs (in LDS), J, redraws, gather, Euler-Maruyama, pin, log-weight -- is
+// ONE launch of one workgroup per chain (the step prologue is shared with the wide path).
+// ------------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ void __launch_bounds__(kBlock) k_lg_step1(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ LgwPreLds pre;
+    const int N = d.N, m = threadIdx.x;
+    const bool live = m < N;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t t0 = kt[6], t1 = kt[7];
+    const int j_ref = d.bs[s + 1];
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    const StepTables<DMAX> t = step_tables<DMAX>(d, s);
+    const float* v_prev = d.vs + (size_t)s * d.dv;
+    const float* v = d.vs + (size_t)(s + 1) * d.dv;
+    const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
+    float xi[DMAX];
+    auto draw_noise = [&]() {
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r)
+            xi[r] = (r < d.du && live) ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r) : 0.0f;
+    };
+    lgw_pre_body<false>(d, s, true, pre, draw_noise);
+    if (live) {
+        const int a = pre.ancS[m];
+        const bool pinned = m == j_ref;
+        float u[DMAX];
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) u[r] = r < d.du ? up[(size_t)r * N + a] : 0.0f;
+        // transition_sampler (gp_gibbs.py:120-122) and the pin of csmc.py:143
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) {
+            if (r < d.du) {
+                const float dr = drift_row<DMAX>(t, r, u, v_prev);
+                float x = (u[r] + dr * t.dt) + t.sd * xi[r];
+                if (pinned) x = ustar[r];
+                un[(size_t)r * N + m] = x;
+                if (d.uss) d.uss[((size_t)(s + 1) * N + m) * d.du + r] = x;
+            }
+        }
+        d.lw[m] = lg_loglik<DMAX>(t, u, v, v_prev);   // likelihood_logpdf on the gathered particle (csmc.py:145)
+    }
+}
+
+// the logsumexp tile partials of the stored log-weights (after the last k_lg_step1, for the final-mode kernels)
+__global__ void __launch_bounds__(kBlock) k_lg_lwpart(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float xch[2][4];
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    float lv[1] = {m < d.N ? d.lw[m] : -__builtin_inff()};
+    float mx, sx;
+    block_lse_partial<1>(lv, xch[0], xch[1], mx, sx);
+    if (threadIdx.x == 0) {
+        d.bmax[blockIdx.x] = mx;
+        d.bsumexp[blockIdx.x] = sx;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1642,9 +1704,16 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     const dim3 gwide(((d.N + kWideTile - 1) / kWideTile) * w_nrt, d.C);
     if (d.wide) k_lgw_init<<<gtile, kBlock, 0, st>>>(d);
     else LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d)));
-    const bool one_tile = d.wide && d.N <= kBlock;   // the steps need no grid-wide stage besides the drift product
-    for (int k = 0; one_tile && k < d.T; ++k) k_lgw_gemm<true><<<gwide, kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
-    if (one_tile) k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);   // log-weights + tile partial for the final-mode kernels
+    const bool one_tile = d.N <= kBlock && !s->generic_prop;   // the steps need no grid-wide stage of their own
+    for (int k = 0; one_tile && k < d.T; ++k) {
+        ProfScope p(s, 2, st);
+        if (d.wide) k_lgw_gemm<true><<<gwide, kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+        else LG_DISPATCH(s, (void)ITEMS; (k_lg_step1<DMAX><<<gone, kBlock, 0, st>>>(d, k)));
+    }
+    if (one_tile) {   // log-weights / tile partial for the final-mode kernels
+        if (d.wide) k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
+        else k_lg_lwpart<<<gtile, kBlock, 0, st>>>(d);
+    }
     for (int k = 0; !one_tile && k < d.T; ++k) {
         if (s->debug_mask & 1) {
             ProfScope p(s, 0, st);
