@@ -31,7 +31,7 @@ def main():
         key, x0, bs, _ = sw.chain(key, x0, toy["y0"], bs, 3, keep=False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 20
+        n = int(os.environ.get("GP100_SWEEPS", "20"))
         key, x0, bs, _ = sw.chain(key, x0, toy["y0"], bs, n, keep=False)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n

@@ -4,6 +4,7 @@
 # command, and two separate PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass).
 # tools/summarise_profiles.py then condenses them into profiles/.
 set -e
+export GP100_SWEEPS=3   # keeps the dispatch count of the counter passes small
 tag=${1:-r01}
 out=$PWD/gpurun_out
 export TMPDIR=/tmp
@@ -12,6 +13,11 @@ tail -c 600 $out/${tag}_bench_stdout.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o run -- python3 bench.py --no-cpu-baseline --no-single-chain --batch-scan "" > $out/${tag}_prof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" > $out/${tag}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" > $out/${tag}_pmc_write.log 2>&1
-find $out/${tag}_prof $out/${tag}_pmc_fetch $out/${tag}_pmc_write -name "*.csv" | head -20
+# LDS bank-conflict counters on the scan kernels (and on the MFMA drift kernel of the d = 100 toy)
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d $out/${tag}_pmc_lds -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" > $out/${tag}_pmc_lds.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d $out/${tag}_pmc_lds_gp100 -o run -- python3 tools/bench_gp100.py 100 > $out/${tag}_pmc_lds_gp100.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_gp100 -o run -- python3 tools/bench_gp100.py 100 10000 > $out/${tag}_prof_gp100.log 2>&1
+find $out/${tag}_prof_gp100 -name "*kernel_trace.csv" -delete
+find $out/${tag}_prof $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc_lds -name "*.csv" | head -20
 # keep the merge-back small: the raw traces are large
 find $out/${tag}_prof -name "*kernel_trace.csv" -delete

@@ -53,6 +53,27 @@ def main():
         w.writerow(["kernel", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "launches"])
         for k in sorted(set(fetch) | set(write)):
             w.writerow([k, fetch.get(k, (0, 0))[0], write.get(k, (0, 0))[0], max(fetch.get(k, (0, 0))[1], write.get(k, (0, 0))[1])])
+    # LDS bank conflicts: cycles stalled by conflicts / cycles the LDS was busy, per kernel
+    for leg, name in (("pmc_lds", "bench"), ("pmc_lds_gp100", "gp100")):
+        try:
+            path = one(f"{tag}_{leg}/**/*counter_collection.csv")
+        except SystemExit:
+            continue
+        conf, act, ins = (pmc_avgs(path, c) for c in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS"))
+        with open(os.path.join(prof, f"{tag}_{name}_pmc_lds.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "SQ_LDS_BANK_CONFLICT_avg", "SQ_LDS_IDX_ACTIVE_avg", "SQ_INSTS_LDS_avg",
+                        "conflict_cycles_per_active_cycle", "launches"])
+            for k in sorted(act):
+                if "fbsmi" not in k:
+                    continue
+                a = act[k][0]
+                w.writerow([k, conf.get(k, (0, 0))[0], a, ins.get(k, (0, 0))[0],
+                            (conf.get(k, (0, 0))[0] / a) if a else 0.0, act[k][1]])
+    try:
+        shutil.copy(one(f"{tag}_prof_gp100/**/*kernel_stats.csv"), os.path.join(prof, f"{tag}_gp100_kernel_stats.csv"))
+    except SystemExit:
+        pass
     cfg = bench["config"]
     prop = [k for k in fetch if "k_lg_prop" in k]
     if not prop:
