@@ -463,6 +463,21 @@ __device__ __forceinline__ void block_lse_partial(const float (&l)[ITEMS], float
 // consumer (up to kMaxTopBlock tiles): lse and the raw global max
 __device__ __forceinline__ void lse_from_partials(const float* __restrict__ pmax, const float* __restrict__ psum, int nb,
                                                   float* lds_a, float* lds_b, float& lse, float& Mraw) {
+    if (nb <= kBlock) {   // one tile per thread: the same canonical tree (zero leaves add exactly), a quarter of the exps
+        const int e = threadIdx.x;
+        const float m1 = e < nb ? pmax[e] : -__builtin_inff();
+        const float s1 = e < nb ? psum[e] : 0.0f;
+        float m = wave_max(m1);
+        if ((threadIdx.x & 63) == 0) lds_a[threadIdx.x >> 6] = m;
+        __syncthreads();
+        Mraw = fmaxf(fmaxf(lds_a[0], lds_a[1]), fmaxf(lds_a[2], lds_a[3]));
+        const float Mp = finite_or_zero_f(Mraw);
+        float sv[1] = {e < nb ? s1 * fbsmi_expf(finite_or_zero_f(m1) - Mp) : 0.0f}, tot[1];
+        TreePath path[1];
+        block_upsweep_n<1>(sv, path, lds_b, tot);
+        lse = fbsmi_logf(tot[0]) + Mp;
+        return;
+    }
     float m4[kTopItems], s4[kTopItems];
     float m = -__builtin_inff();
 #pragma unroll

@@ -210,7 +210,12 @@ __global__ void __launch_bounds__(kBlock) k_lg_keys(LgDev dd, int chain) {
         split_at(q0, q1, 2, 1, kt[6], kt[7]);  // key_transition
         split_at(r0, r1, 3, 0, kt[0], kt[1]);
         split_at(r0, r1, 3, 1, kt[2], kt[3]);
-        split_at(r0, r1, 3, 2, kt[4], kt[5]);
+        // key_3 draws the single uniform of the rotation J (resamplings.py:84): draw it here, once per sweep,
+        // instead of once per thread of every step kernel
+        uint32_t c0, c1;
+        split_at(r0, r1, 3, 2, c0, c1);
+        kt[4] = __float_as_uint(uniform_at(c0, c1, 1, 0));
+        kt[5] = 0;
     }
 }
 
@@ -619,7 +624,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev dd, int s) {
     __shared__ float heapW[kHeapSize], heapJ[kHeapSize];
     const int N = d.N;
     const uint32_t* kt = d.keytab + 8 * s;
-    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5], t0 = kt[6], t1 = kt[7];
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], t0 = kt[6], t1 = kt[7];
     const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
     const float lastJ = d.cdfJ[N - 1];
     const float last = d.cdf[N - 1];
@@ -641,7 +646,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop(LgDev dd, int s) {
     // gathers are outstanding
     constexpr bool kHoistNoise = ITEMS * DMAX <= 16;   // more than that would spill
     float xi[kHoistNoise ? ITEMS : 1][kHoistNoise ? DMAX : 1];
-    const float u3 = uniform_at(c0, c1, 1, 0);
+    const float u3 = __uint_as_float(kt[4]);
     if (kHoistNoise) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i)
@@ -732,7 +737,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
     FBSMI_STAMP(6)
     const int N = d.N;
     const uint32_t* kt = d.keytab + 8 * s;
-    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5], t0 = kt[6], t1 = kt[7];
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], t0 = kt[6], t1 = kt[7];
     const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
     const int m = blockIdx.x * kBlock + threadIdx.x;
     const bool live = m < N;
@@ -758,7 +763,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
     const float* v_prev = d.vs + (size_t)s * d.dv;
     const float* v = d.vs + (size_t)(s + 1) * d.dv;
     const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
-    const float u3 = uniform_at(c0, c1, 1, 0);
+    const float u3 = __uint_as_float(kt[4]);
     float xi[DMAX];
 #pragma unroll
     for (int r = 0; r < DMAX; ++r)
@@ -936,7 +941,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_anc(LgDev dd, int s) {
     __shared__ float heapW[kHeapSizeW], heapJ[kHeapSizeJ], win[kBlock];
     const int N = d.N, t = threadIdx.x;
     const uint32_t* kt = d.keytab + 8 * s;
-    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5];
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3];
     const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
     const int m = blockIdx.x * kBlock + t;
     const bool live = m < N;
@@ -952,7 +957,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_anc(LgDev dd, int s) {
         hw[h] = (node >= 1 && node < nodesW) ? d.hpW[node] : 0.0f;
     }
     const float hj = (t >= 1 && t < nodesJ) ? d.hpJ[t] : 0.0f;
-    const float u3 = uniform_at(c0, c1, 1, 0);
+    const float u3 = __uint_as_float(kt[4]);
 #pragma unroll
     for (int h = 0; h < kPerThread; ++h) heapW[t + h * kBlock] = hw[h];
     heapJ[t] = hj;
@@ -999,7 +1004,7 @@ template <bool ROWS, typename Early>
 __device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, LgwPreLds& L, Early early) {
     const int N = d.N, t = threadIdx.x;
     const uint32_t* kt = d.keytab + 8 * s;
-    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], c0 = kt[4], c1 = kt[5];
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3];
     const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
     const bool live = t < N;
     FBSMI_STAMP(25)
@@ -1013,7 +1018,7 @@ __device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, 
     // in the shadow of those loads: the caller's work and the three uniforms of this thread -- as a SOURCE
     // slot p = t it owns the kill test and the redraw of p (resamplings.py:71-74), whatever the rotation
     early();
-    const float u3 = uniform_at(c0, c1, 1, 0);
+    const float u3 = __uint_as_float(kt[4]);
     const float u1 = live ? uniform_at(a0, a1, (uint64_t)N, (uint64_t)t) : 0.0f;
     const float u2 = live ? uniform_at(b0, b1, (uint64_t)N, (uint64_t)t) : 0.0f;
     if (ROWS && live && s) {
