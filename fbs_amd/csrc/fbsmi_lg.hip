@@ -72,6 +72,7 @@ struct LgDev {
     float* cdfJ;       // [N]
     float *bmax, *bsumexp, *bsumw, *bsumJ;  // [nb]
     float *hpW, *hpJ;                       // compact bisection heaps of cdf / cdfJ (one slot per thread only)
+    const int32_t* hp_map;                  // [N] heap node (low 16 bits) and depth (high) an element is the midpoint of, or 0
     int wide;                               // 16 < max(du, dv) <= 128: row-major particles u0/u1 [N][du], MFMA drift
     float* lpw;                             // [N][dv rounded up to 4] per-row log-density terms of the wide path
     int32_t* anc;                           // [N] ancestors of the current step (wide path)
@@ -522,24 +523,13 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
         return;
     }
     // ---- MODE 0
-    // Which node of the implicit bisection tree is this element the midpoint of (if any, within the
-    // heap depth)?  Index arithmetic only, done in the shadow of the loads.  Down to depth
-    // floor(log2 N) every node is at least two wide, so an element is the midpoint of at most one.
+    // Which node of the implicit bisection tree is this element the midpoint of (if any, within the heap
+    // depth)?  A property of (N, element) alone: tabulated once at handle creation (heap_map()).
     int hp_node = 0, hp_depth = 0;
     if (ITEMS == 1 && d.hpW && base < d.N) {
-        int lo = 0, hi = d.N, t = 1;
-        for (int l = 0; l < d.lh_w; ++l) {
-            const int mid = (lo + hi) >> 1;
-            if (base == mid) {
-                hp_node = t;
-                hp_depth = l;
-                break;
-            }
-            const bool left = base < mid;
-            hi = left ? mid : hi;
-            lo = left ? lo : mid;
-            t = 2 * t + (left ? 0 : 1);
-        }
+        const int hm = d.hp_map[base];
+        hp_node = hm & 0xFFFF;
+        hp_depth = hm >> 16;
     }
     const int b_ref = i_ref / TILE;
     const int rbase = b_ref * TILE + threadIdx.x * ITEMS;
@@ -1897,12 +1887,15 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         rc |= slab_request(s, &d.anc, C * N);
     }
     d.hpW = d.hpJ = nullptr;
+    d.hp_map = nullptr;
+    int32_t* hp_map_dev = nullptr;
     d.lh_w = d.lh_j = 0;
     if (s->items == 1) {
         int fl = 0;
         while ((2ll << fl) <= (long long)d.N) ++fl;   // floor(log2 N)
         d.lh_w = fl < kHeapLevelsW ? fl : kHeapLevelsW;
         d.lh_j = fl < kHeapLevelsJ ? fl : kHeapLevelsJ;
+        rc |= slab_request(s, &hp_map_dev, (size_t)N);
         rc |= slab_request(s, &d.hpW, C * (size_t)kHeapSizeW);
         rc |= slab_request(s, &d.hpJ, C * (size_t)kHeapSizeJ);
     }
@@ -1923,6 +1916,24 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         rc |= slab_request(s, &d.lwss, C * (T + 1) * N);
     }
     rc |= slab_commit(s);
+    if (!rc && hp_map_dev) {
+        // Down to depth floor(log2 N) every node of the implicit bisection tree is at least two wide, so an
+        // element is the midpoint of at most one node there: walk the tree once, on the host.
+        std::vector<int32_t> map((size_t)d.N, 0);
+        struct Node { int lo, hi, t, dep; };
+        std::vector<Node> stack{{0, d.N, 1, 0}};
+        while (!stack.empty()) {
+            const Node n = stack.back();
+            stack.pop_back();
+            if (n.dep >= d.lh_w) continue;
+            const int mid = (n.lo + n.hi) >> 1;
+            map[mid] = n.t | (n.dep << 16);
+            stack.push_back({n.lo, mid, 2 * n.t, n.dep + 1});
+            stack.push_back({mid, n.hi, 2 * n.t + 1, n.dep + 1});
+        }
+        if (hipMemcpy(hp_map_dev, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice) != hipSuccess) rc = 1;
+        d.hp_map = hp_map_dev;
+    }
     if (rc) {
         fbsmi_lg_sweep_destroy(s);
         return FBSMI_ERR_HIP;
