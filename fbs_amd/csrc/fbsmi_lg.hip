@@ -1081,23 +1081,81 @@ __device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, 
     FBSMI_STAMP(29)
 }
 
+// The same for the particle filters (bootstrap_filter smc.py:58-74, pmcmc_filter_step smc.py:138-152): row
+// sums -> c = logsumexp -> log-likelihood accumulator -> w -> cumsum -> stratified / systematic ancestors
+// (resampling.py:43-51) with the resampling key of step `kres`.  Call for call the arithmetic of
+// k_lgw_lse -> k_filt_norm<1> -> k_lg_cdf<1,2> -> the search of k_filt_prop with one tile.
+template <typename Early>
+__device__ __forceinline__ void lgw_fpre_body(const LgDev& d, int kres, bool store, LgwPreLds& L, Early early) {
+    const int N = d.N, t = threadIdx.x;
+    const uint32_t r0 = d.keytab[8 * kres + 2], r1 = d.keytab[8 * kres + 3];
+    const bool live = t < N;
+    LgwRowLoads rows;
+    if (live) lgw_row_issue(d, t, rows);
+    early();
+    float uu = 0.0f;
+    if (d.systematic) uu = uniform_at(r0, r1, 1, 0);
+    else if (live) uu = uniform_at(r0, r1, (uint64_t)N, (uint64_t)t);
+    float l = 0.0f;
+    if (live) {
+        l = lgw_row_add(d, rows);
+        if (store) d.lw[t] = l;
+    }
+    float lv[1] = {live ? l : -__builtin_inff()};
+    float Mraw, sx;
+    block_lse_partial<1>(lv, L.xch[0], L.xch[1], Mraw, sx);
+    const float c = fbsmi_logf(sx) + finite_or_zero_f(Mraw);
+    if (store && t == 0) {
+        const float e0 = *d.ell;
+        *d.ell = d.flow == 0 ? e0 - (c - d.logn)      // log_nell -= _c - log(N)          smc.py:67
+                             : (e0 - d.logn) + c;      // log_ell = log_ell - log(N) + _c  smc.py:146
+    }
+    const float w = live ? fbsmi_expf(l - c) : 0.0f;   // smc.py:68-69 / :147-148
+    if (store && live) d.w[t] = w;
+    float s1[1] = {w}, t1[1];
+    TreePath p1[1];
+    block_upsweep_n<1>(s1, p1, L.xch[2], t1);
+    {
+        float P = 0.0f, E = t1[0], cc[1];
+        const float xw1[1] = {w};
+        block_descend(P, E, p1[0]);
+        chunk_scan<1>(xw1, P, E, cc);
+        L.cW[t] = cc[0];
+    }
+    __syncthreads();
+    int a = -1;
+    if (live) {
+        const float q = ((float)t + uu) / (float)N;
+        a = searchsorted_left(L.cW, N, d.levels, q);
+        a = a < 0 ? 0 : (a > N - 1 ? N - 1 : a);
+    }
+    L.ancS[t] = a;
+    __syncthreads();
+}
+
 // The drift product and what hangs on it.  nrt = row tiles = ceil(D / 32); Kp = D rounded up to a multiple of
 // 16, Q = Kp / 4.  LDS tiles are [32][S] with column c stored at (c % 4) * Q + c / 4: lane group g of an
 // MFMA (which supplies column 4q + g of instruction q) then finds its columns of four consecutive
 // instructions in one aligned float4.  S % 64 == 4: the 16 lanes of a ds_read_b128 pass cover all 64 banks.
-template <bool FUSED>
-__global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, int Kp, int S) {
+// KIND: where the ancestors come from -- 0: d.anc (k_lgw_anc); 1: the Gibbs step prologue, in this
+// workgroup; 2: the filter prologue (resampling key of step kres), in this workgroup; 3: identity (no
+// resampling in front of this product).  tr0 / nrt: the row tiles of this launch; emit bit 0: rows < du
+// are written (new particles), bit 1: rows >= du are written (log-density terms).
+template <int KIND>
+__global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, int nrt, int Kp, int S, int emit, int kres) {
+    constexpr bool FUSED = KIND == 1;
+    constexpr bool FILT = KIND >= 2;
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ LgwPreLds pre;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* Gs = dyn;                    // [32 rows][S]: rows 32*tr .. of G_s
     float* Zs = dyn + kWideTile * S;    // [32 slots][S]: z = (u[ancestor], v_prev)
     const int N = d.N, du = d.du, D = d.D;
-    const int ts = blockIdx.x / nrt, tr = blockIdx.x - ts * nrt;
+    const int ts = blockIdx.x / nrt, tr = tr0 + (blockIdx.x - ts * nrt);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t* kt = d.keytab + 8 * s;
-    const uint32_t t0 = kt[6], t1 = kt[7];
-    const int j_ref = d.bs[s + 1];
+    const uint32_t t0 = kt[FILT ? 0 : 6], t1 = kt[FILT ? 1 : 7];   // key_transition (Gibbs) / key_proposal (filters)
+    const int j_ref = FILT ? -1 : d.bs[s + 1];
     const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
     float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
     const float* __restrict__ G = d.G + (size_t)s * D * D;
@@ -1113,11 +1171,11 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
     //      ancestor rows (the only dependent loads) go out as soon as the ancestors are here.
     constexpr int kRows = kWideTile / kWaves;   // 8 rows / slots per wave
     int an[kRows];
-    if (!FUSED) {
+    if (KIND == 0 || KIND == 3) {
 #pragma unroll
         for (int jj = 0; jj < kRows; ++jj) {
             const int mj = kWideTile * ts + wave + kWaves * jj;
-            an[jj] = mj < N ? d.anc[mj] : -1;
+            an[jj] = mj < N ? (KIND == 0 ? d.anc[mj] : mj) : -1;
         }
     }
     const bool vec4 = (D & 3) == 0 && (du & 3) == 0;   // rows are whole float4s: one load per lane and row
@@ -1152,12 +1210,13 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
 #pragma unroll
         for (int vv = 0; vv < 4; ++vv) {
             const int r = row0 + vv;
-            xi[vv] = (r < du && mo < N) ? normal_at(t0, t1, (uint64_t)N * du, (uint64_t)mo * du + r) : 0.0f;
+            xi[vv] = (r < du && mo < N && (emit & 1)) ? normal_at(t0, t1, (uint64_t)N * du, (uint64_t)mo * du + r) : 0.0f;
         }
     };
-    if (!FUSED) draw_noise();
-    if (FUSED) {   // the G tile is on its way; now the step's ancestors, worked out by this workgroup itself
-        lgw_pre_body<true>(d, s, blockIdx.x == 0, pre, draw_noise);
+    if (KIND == 0 || KIND == 3) draw_noise();
+    if (KIND == 1 || KIND == 2) {   // the G tile is on its way; now the step's ancestors, worked out by this workgroup itself
+        if (KIND == 1) lgw_pre_body<true>(d, s, blockIdx.x == 0, pre, draw_noise);
+        else lgw_fpre_body(d, kres, blockIdx.x == 0, pre, draw_noise);
 #pragma unroll
         for (int jj = 0; jj < kRows; ++jj) {
             const int mj = kWideTile * ts + wave + kWaves * jj;
@@ -1182,6 +1241,14 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
             float z = 0.0f;
             if (a >= 0 && c < D) z = c < du ? up[(size_t)a * du + c] : v_prev[c - du];
             zq[q] = z;
+        }
+    }
+    if (FILT && d.uss && d.flow == 0 && s > 0 && tr == tr0) {   // filtering_samples[s] = the resampled particles (smc.py:72,84)
+#pragma unroll
+        for (int q = 0; q < kRows * 4; ++q) {
+            const int mj = kWideTile * ts + wave + kWaves * (q >> 2);
+            const int c = vec4 ? 4 * lane + (q & 3) : lane + 64 * (q & 3);
+            if (mj < N && c < du) d.uss[((size_t)s * N + mj) * du + c] = zq[q];
         }
     }
     FBSMI_STAMP(21)
@@ -1220,11 +1287,14 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
         for (int vv = 0; vv < 4; ++vv) {
             const int r = row0 + vv;
             if (r < du) {
-                float x = (Zs[jloc * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
-                if (pinned) x = ustar[r];
-                un[(size_t)mo * du + r] = x;
-                if (d.uss) d.uss[((size_t)(s + 1) * N + mo) * du + r] = x;
-            } else if (r < D) {
+                if (emit & 1) {
+                    float x = (Zs[jloc * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
+                    if (pinned) x = ustar[r];
+                    un[(size_t)mo * du + r] = x;
+                    if (!FILT && d.uss) d.uss[((size_t)(s + 1) * N + mo) * du + r] = x;
+                    if (FILT && d.flow == 1 && s == d.T - 1) d.usT[(size_t)mo * du + r] = x;
+                }
+            } else if (r < D && (emit & 2)) {
                 const int rv = r - du;
                 const float cond_m = v_prev[rv] + acc[vv] * d.dt;
                 d.lpw[(size_t)mo * ((d.dv + 3) & ~3) + rv] = norm_logpdf(v[rv], cond_m, sd2, lognorm);
@@ -1232,6 +1302,33 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int nrt, i
         }
     }
     FBSMI_STAMP(24)
+}
+
+// wide particle filters: initial particles (n, du) row-major -> u0 (same layout) [+ filtering path slot 0]
+__global__ void __launch_bounds__(kBlock) k_lgwf_init(LgDev dd, const float* u0s_all) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    const float* u0s = u0s_all + (size_t)blockIdx.y * d.N * d.du;
+    const size_t tot = (size_t)d.N * d.du;
+    for (size_t e = blockIdx.x * (size_t)kBlock + threadIdx.x; e < tot; e += (size_t)gridDim.x * kBlock) {
+        const float v = u0s[e];
+        d.u0[e] = v;
+        if (d.uss) d.uss[e] = v;
+    }
+}
+
+// bootstrap_filter's last act: normalise the last weights, resample, return us[inds] (smc.py:66-72 of the last step)
+__global__ void __launch_bounds__(kBlock) k_lgwf_final(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ LgwPreLds pre;
+    lgw_fpre_body(d, d.T - 1, true, pre, []() {});
+    const float* __restrict__ up = (d.T & 1) ? d.u1 : d.u0;
+    const int tot = d.N * d.du;
+    for (int e = threadIdx.x; e < tot; e += kBlock) {
+        const int m = e / d.du, r = e - m * d.du;
+        const float x = up[(size_t)pre.ancS[m] * d.du + r];
+        d.usT[e] = x;
+        if (d.uss) d.uss[(size_t)d.T * tot + e] = x;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1702,7 +1799,7 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     const bool one_tile = d.N <= kBlock && !s->generic_prop;   // the steps need no grid-wide stage of their own
     for (int k = 0; one_tile && k < d.T; ++k) {
         ProfScope p(s, 2, st);
-        if (d.wide) k_lgw_gemm<true><<<gwide, kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+        if (d.wide) k_lgw_gemm<1><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
         else LG_DISPATCH(s, (void)ITEMS; (k_lg_step1<DMAX><<<gone, kBlock, 0, st>>>(d, k)));
     }
     if (one_tile) {   // log-weights / tile partial for the final-mode kernels
@@ -1722,7 +1819,7 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
             ProfScope p(s, 2, st);
             if (d.wide) {
                 k_lgw_anc<<<gtile, kBlock, 0, st>>>(d, k);
-                k_lgw_gemm<false><<<gwide, kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+                k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
                 k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
             } else if (s->items == 1 && !s->generic_prop) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
@@ -1946,11 +2043,11 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     }
     if (wide) {
         const int Kp = (d.D + 15) / 16 * 16, S = Kp + ((68 - Kp % 64) % 64);
-        hipError_t e = hipFuncSetAttribute((const void*)k_lgw_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(sizeof(float) * 2 * kWideTile * S));
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)k_lgw_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(float) * 2 * kWideTile * S));
+        const int lds = (int)(sizeof(float) * 2 * kWideTile * S);
+        hipError_t e = hipFuncSetAttribute((const void*)k_lgw_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             fbsmi_lg_sweep_destroy(s);
             return fail(FBSMI_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
@@ -2073,6 +2170,34 @@ int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
     const LgDev& d = s->d;
     const dim3 gone(1, d.C), gtile(d.nb, d.C);
     k_filt_keys<<<gone, kBlock, 0, st>>>(d);
+    if (d.wide) {
+        // one-tile ensembles only (checked at creation): a launch = [filter prologue +] drift product
+        const int nrt = (d.D + kWideTile - 1) / kWideTile, Kp = (d.D + 15) / 16 * 16, S = Kp + ((68 - Kp % 64) % 64);
+        const size_t lds = sizeof(float) * 2 * kWideTile * (size_t)S;
+        const int nst = (d.N + kWideTile - 1) / kWideTile;
+        const int u_tiles = (d.du + kWideTile - 1) / kWideTile;   // row tiles holding rows < du
+        const int v_tile0 = d.du / kWideTile;                     // first row tile holding rows >= du
+        k_lgwf_init<<<dim3(8, d.C), kBlock, 0, st>>>(d, f->u0s);
+        if (d.flow == 0) {
+            for (int k = 0; k < d.T; ++k) {
+                if (k == 0) k_lgw_gemm<3><<<dim3(nst * nrt, d.C), kBlock, lds, st>>>(d, k, 0, nrt, Kp, S, 3, 0);
+                else k_lgw_gemm<2><<<dim3(nst * nrt, d.C), kBlock, lds, st>>>(d, k, 0, nrt, Kp, S, 3, k - 1);
+            }
+            k_lgwf_final<<<gone, kBlock, 0, st>>>(d);
+        } else {
+            // weight the current particles (rows >= du, no resampling), then resample + propagate (rows < du)
+            k_lgw_gemm<3><<<dim3(nst * (nrt - v_tile0), d.C), kBlock, lds, st>>>(d, 0, v_tile0, nrt - v_tile0, Kp, S, 2, 0);
+            for (int k = 0; k < d.T; ++k) {
+                k_lgw_gemm<2><<<dim3(nst * u_tiles, d.C), kBlock, lds, st>>>(d, k, 0, u_tiles, Kp, S, 1, k);
+                if (k + 1 < d.T)
+                    k_lgw_gemm<3><<<dim3(nst * (nrt - v_tile0), d.C), kBlock, lds, st>>>(d, k + 1, v_tile0, nrt - v_tile0, Kp,
+                                                                                          S, 2, 0);
+            }
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("filter launch: ") + hipGetErrorString(e));
+        return FBSMI_OK;
+    }
     LG_DISPATCH(s, (k_filt_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, f->u0s)));
     for (int k = 0; k < d.T; ++k) {
         if (d.flow == 0)
@@ -2096,6 +2221,8 @@ int fbsmi_lg_filter_create(const fbsmi_lg_model* m, int32_t nparticles, int flow
     if (!out || flow < 0 || flow > 1 || resampling < 0 || resampling > 1)
         return fail(FBSMI_ERR_ARG, "lg_filter_create: flow must be 0|1 and resampling 0 (stratified) | 1 (systematic)");
     if (flow == 1 && store_path) return fail(FBSMI_ERR_ARG, "lg_filter_create: pmcmc_filter_step keeps no path");
+    if (m && (m->du > 16 || m->dv > 16) && nparticles > kBlock)
+        return fail(FBSMI_ERR_UNSUPPORTED, "lg_filter: du, dv > 16 with more than 256 particles is not supported by the fused filters");
     fbsmi_lg_sweep* core = nullptr;
     int rc = fbsmi_lg_sweep_create(m, nparticles, 1, 0, store_path, nchains, &core);
     if (rc) return rc;

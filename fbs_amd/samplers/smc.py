@@ -16,12 +16,12 @@ from . import resampling as _resampling
 from .common import MCMCState
 
 
-def _fused_filter(transition_sampler, weight_closure, resampling, kwargs):
+def _fused_filter(transition_sampler, weight_closure, resampling, kwargs, nparticles):
     """(model, resampling name) when the fused analytic-model filter applies, else None."""
     model = getattr(transition_sampler, "_fbsmi_lg", None)
     if model is None or getattr(weight_closure, "_fbsmi_lg", None) is not model or kwargs:
         return None
-    if getattr(weight_closure, "_role", "") != "likelihood_logpdf" or max(model.du, model.dv) > 16:
+    if getattr(weight_closure, "_role", "") != "likelihood_logpdf" or not model.fused_filter_supported(nparticles):
         return None
     name = "stratified" if resampling is _resampling.stratified else (
         "systematic" if resampling is _resampling.systematic else None)
@@ -32,7 +32,7 @@ def bootstrap_filter(transition_sampler, measurement_cond_pdf, vs, ts, init_samp
                      log: bool = True, return_last: bool = True, **kwargs):
     """Bootstrap particle filter (smc.py:9-88) -> (samples, negative log-likelihood)."""
     nsteps = vs.shape[0] - 1
-    fused = _fused_filter(transition_sampler, measurement_cond_pdf, resampling, kwargs) if log else None
+    fused = _fused_filter(transition_sampler, measurement_cond_pdf, resampling, kwargs, nparticles) if log else None
     if fused is not None and fused[0].T == nsteps:
         model, rname = fused
         key_init, _ = ops.split(key, 2)                                             # :77
@@ -84,7 +84,7 @@ def pmcmc_filter_step(key, vs_bridge, u0s, ts, transition_sampler, likelihood_lo
                       **kwargs):
     """Particle filter inside pMCMC (smc.py:115-158): weight -> resample old -> propagate."""
     nsteps = (ts.shape[0] if hasattr(ts, "shape") else len(ts)) - 1
-    fused = _fused_filter(transition_sampler, likelihood_logpdf, resampling, kwargs)
+    fused = _fused_filter(transition_sampler, likelihood_logpdf, resampling, kwargs, nparticles)
     if fused is not None and fused[0].T == nsteps:
         model, rname = fused
         uT, ell = model.filter_handle(nparticles, "pmcmc", rname).run(key, vs_bridge, u0s)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import toy_2d, toy_4d, oracle_model_from
+from helpers import toy_gp, toy_2d, toy_4d, oracle_model_from
 
 pytestmark = pytest.mark.gpu
 
@@ -262,7 +262,10 @@ def test_sharded_module_world1_on_gpu(oracle, dev):
 
 
 @pytest.mark.parametrize("resampling", ["stratified", "systematic"])
-@pytest.mark.parametrize("toy,n,T", [(toy_2d, 128, 30), (toy_4d, 1000, 12), (toy_2d, 70000, 6)])
+@pytest.mark.parametrize("toy,n,T", [(toy_2d, 128, 30), (toy_4d, 1000, 12), (toy_2d, 70000, 6),
+                                     (lambda: toy_gp(100), 100, 8),      # the reference's gp_filter / gp_pmcmc scale
+                                     (lambda: toy_gp(33, 17), 37, 6),    # wide, odd sizes, tiles straddling du
+                                     (lambda: toy_gp(20), 256, 5)])
 def test_fused_filters_match_oracle(toy, n, T, resampling, oracle, dev):
     """The fused (hipGraph) bootstrap_filter / pmcmc_filter_step of the analytic model, reached through
     the unchanged fbs_amd.samplers.smc signatures, against the oracle -- and against the closure tier."""

@@ -38,6 +38,25 @@ def main():
         flops = 2.0 * N * (2 * d) ** 2 * T * C
         print(f"d=100 N={N:6d} T={T} chains={C}: {dt * 1e3:8.3f} ms/sweep = {dt / T * 1e6:7.2f} us/step, "
               f"{N * T * C / dt:.3e} particle-steps/s, drift {flops / dt / 1e12:.2f} TFLOP/s (f32 MFMA peak 157)")
+    # the particle filters of the same experiment family (gp_filter.py: one bootstrap filter per sample;
+    # gp_pmcmc.py: one pmcmc_filter_step per MCMC iteration), nparticles = 100
+    from fbs_amd.samplers import smc
+    from fbs_amd.samplers import resampling as R
+    N = 100
+    y0 = torch.from_numpy(toy["y0"]).to(dev)
+    vs = torch.flip(br.fwd_ys_sampler(ops.PRNGKey(5), y0), [0])
+    init = ops.normal(ops.PRNGKey(6), (N, d), device=dev)
+    for name, fn in (("bootstrap_filter", lambda k: smc.bootstrap_filter(br.transition_sampler, br.likelihood_logpdf, vs, ts,
+                                                                            lambda k_, v0, n_: init, k, N, R.stratified)),
+                     ("pmcmc_filter_step", lambda k: smc.pmcmc_filter_step(k, vs, init, ts, br.transition_sampler,
+                                                                            br.likelihood_logpdf, R.stratified, N))):
+        fn(ops.PRNGKey(7))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(20):
+            fn(ops.PRNGKey(8 + i))
+        torch.cuda.synchronize()
+        print(f"d=100 N={N} T={T} {name}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per run (one chain)")
     if len(sys.argv) > 1:
         return
     # closure tier for one chain at N = 100 (host loop, generic kernels)
