@@ -76,6 +76,9 @@ CASES = [
     (toy_4d, 300, 50, 2.0, False, True),
     (toy_31, 513, 25, 1.0, True, False),
     (toy_2d, 200000, 12, 1.0, True, False),   # ITEMS = 4 kernels
+    (toy_4d, 256, 9, 1.0, True, False),       # the largest single-launch-per-step ensemble
+    (toy_4d, 255, 9, 1.0, False, True),       # ... with explicit_final: N + 1 = 256 slots
+    (toy_31, 257, 9, 1.0, True, False),       # just past it: three launches per step, two tiles
 ]
 
 
@@ -112,6 +115,12 @@ WIDE_CASES = [
     (33, 17, 77, 8, True),        # odd sizes: D = 50 is not a multiple of 4, row tiles straddle du
     (17, 5, 40, 8, False),        # stored path + backward scanning
     (128, 128, 33, 3, True),      # the largest supported model
+    (24, 24, 1, 4, True),         # a single particle
+    (24, 24, 2, 4, False),
+    (40, 40, 32, 4, True),        # exactly one slot tile
+    (40, 40, 256, 4, True),       # the largest single-launch-per-step ensemble
+    (40, 40, 257, 4, True),       # just past it: five launches per step
+    (30, 18, 700, 5, False),      # several logsumexp tiles, stored path
 ]
 
 
