@@ -175,19 +175,25 @@ def main():
         net = {k: max(v - c_ev, 1e-3) for k, v in raw.items()}
         prop_us = net["prop"]
         achieved = prop_bytes / (prop_us * 1e-6) / 1e9
-        traffic = None
+        traffic, valu_insts = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_lg_prop_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("k_lg_prop_bytes_per_launch")
+                valu_insts = tj.get("k_lg_prop_valu_insts_per_launch")
             except Exception:
                 traffic = None
+        # VALU issue roof: one wave64 instruction per CU per clock (4 SIMDs x 1 per 4 clocks), 256 CUs at ~2.4 GHz;
+        # f64 instructions (the exp of the numeric spec) take two slots, so this is a lower bound on the occupancy
+        valu_frac = (valu_insts / (256.0 * 2.4e3 * prop_us)) if (valu_insts and C == 4) else None
         roofline = {"bound": "hbm", "kernel": "k_lg_prop (resample + gather + Euler-Maruyama + log-weight)",
                     "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                     "traffic": traffic, "bytes_per_launch": prop_bytes, "avg_launch_us": prop_us,
                     "timing": "hipEvent pairs around each launch on the launch stream, net of the event overhead "
                               "calibrated against the graph-timed step (see bench.py)",
                     "event_overhead_us": c_ev, "raw_event_us": raw, "kernels_us": net,
+                    "valu_issue_frac": valu_frac,
                     "whole_sweep_GBps": bpp["step"] * float(N) * T * C / (ms_per_step * 1e-3) / 1e9,
                     "note": "working set per step is a few MB (cache-resident) and the kernel is latency- then "
                             "VALU-bound (in-kernel Threefry + erf_inv), not HBM-bound: see DESIGN.md"}

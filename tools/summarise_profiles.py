@@ -74,6 +74,26 @@ def main():
         shutil.copy(one(f"{tag}_prof_gp100/**/*kernel_stats.csv"), os.path.join(prof, f"{tag}_gp100_kernel_stats.csv"))
     except SystemExit:
         pass
+    # instruction mix per wave of the step kernels
+    valu_json = None
+    try:
+        path = one(f"{tag}_pmc_valu/**/*counter_collection.csv")
+        names = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES")
+        cols = {n: pmc_avgs(path, n) for n in names}
+        valu_json = {}
+        with open(os.path.join(prof, f"{tag}_bench_pmc_valu.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "waves_per_launch"] + [n + "_per_wave" for n in names[:-1]] + ["launches"])
+            for k in sorted(cols["SQ_WAVES"]):
+                if "fbsmi" not in k:
+                    continue
+                wv = cols["SQ_WAVES"][k][0]
+                per = [cols[n].get(k, (0, 0))[0] / wv if wv else 0.0 for n in names[:-1]]
+                w.writerow([k, wv] + per + [cols["SQ_WAVES"][k][1]])
+                if "k_lg_prop" in k or "<1, 0>" in k:
+                    valu_json[k] = {"waves_per_launch": wv, "valu_per_wave": per[0], "salu_per_wave": per[1]}
+    except SystemExit:
+        pass
     cfg = bench["config"]
     prop = [k for k in fetch if "k_lg_prop" in k]
     if not prop:
@@ -93,6 +113,11 @@ def main():
                 "correction for 16-B-per-lane streaming reads, these kernels move 4 B per lane.  The counters sit on "
                 "the memory side of the XCD L2s (Infinity-Cache hits included).",
     }
+    if valu_json:
+        pk = [kk for kk in valu_json if "k_lg_prop" in kk]
+        if pk:
+            traffic["k_lg_prop_valu_insts_per_launch"] = valu_json[pk[0]]["valu_per_wave"] * valu_json[pk[0]]["waves_per_launch"]
+        traffic["step_kernels_instruction_mix"] = valu_json
     json.dump(traffic, open(os.path.join(prof, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
     print(open(os.path.join(prof, f"{tag}_bench_kernel_stats.csv")).read()[:1500])
