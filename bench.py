@@ -50,7 +50,7 @@ def max_over_ranks(dt, dist, dev):
     """The timed region's duration is the slowest rank's."""
     if dist is None:
         return dt
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return float(tt.item())
 
@@ -111,13 +111,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the sampler engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # one rank per GPU over RCCL; FBSMI_BENCH_BACKEND=gloo lets the multi-rank path be rehearsed on one GPU
+        backend = os.environ.get("FBSMI_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import fbs_amd
     from fbs_amd.sdes import StationaryConstLinearSDE
