@@ -1337,9 +1337,7 @@ __global__ void __launch_bounds__(kBlock) k_lgwf_final(LgDev dd) {
 // ONE launch of one workgroup per chain (the step prologue is shared with the wide path).
 // ------------------------------------------------------------------------------------------
 template <int DMAX>
-__global__ void __launch_bounds__(kBlock) k_lg_step1(LgDev dd, int s) {
-    const LgDev d = chain_view(dd, blockIdx.y);
-    __shared__ LgwPreLds pre;
+__device__ __forceinline__ void lg_step1_body(const LgDev& d, int s, LgwPreLds& pre) {
     const int N = d.N, m = threadIdx.x;
     const bool live = m < N;
     const uint32_t* kt = d.keytab + 8 * s;
@@ -1376,6 +1374,26 @@ __global__ void __launch_bounds__(kBlock) k_lg_step1(LgDev dd, int s) {
             }
         }
         d.lw[m] = lg_loglik<DMAX>(t, u, v, v_prev);   // likelihood_logpdf on the gathered particle (csmc.py:145)
+    }
+}
+
+template <int DMAX>
+__global__ void __launch_bounds__(kBlock) k_lg_step1(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ LgwPreLds pre;
+    lg_step1_body<DMAX>(d, s, pre);
+}
+
+// ... and, since one workgroup owns the chain, all T steps in ONE launch: a workgroup barrier is the only
+// synchronisation a step needs (its own stores are visible to its own waves: they share the CU's L1).
+template <int DMAX>
+__global__ void __launch_bounds__(kBlock) k_lg_sweep1(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ LgwPreLds pre;
+    for (int s = 0; s < d.T; ++s) {
+        lg_step1_body<DMAX>(d, s, pre);
+        __threadfence_block();
+        __syncthreads();
     }
 }
 
@@ -1692,6 +1710,7 @@ struct fbsmi_lg_sweep {
     hipGraphExec_t graph_single = nullptr;  // one sweep, no chain bookkeeping
     hipGraphExec_t graph_chain = nullptr;   // one sweep + key split + advance
     bool profile = false;
+    bool step_launches = false;  // FBSMI_STEP_LAUNCHES=1: one launch per step also where one launch per sweep is possible
     bool generic_prop = false;  // FBSMI_GENERIC_PROP=1: k_lg_prop also for one slot per thread (timing experiments)
     int debug_mask = 7;  // FBSMI_DEBUG_STEP_MASK: bit0 norm, bit1 cdf, bit2 prop (timing experiments only)
     std::vector<hipEvent_t> prof_ev[kNumProfKernels];  // pairs (start, stop)
@@ -1797,7 +1816,9 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     if (d.wide) k_lgw_init<<<gtile, kBlock, 0, st>>>(d);
     else LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d)));
     const bool one_tile = d.N <= kBlock && !s->generic_prop;   // the steps need no grid-wide stage of their own
-    for (int k = 0; one_tile && k < d.T; ++k) {
+    const bool persistent = one_tile && !d.wide && !s->profile && !s->step_launches;
+    if (persistent) LG_DISPATCH(s, (void)ITEMS; (k_lg_sweep1<DMAX><<<gone, kBlock, 0, st>>>(d)));
+    for (int k = 0; one_tile && !persistent && k < d.T; ++k) {
         ProfScope p(s, 2, st);
         if (d.wide) k_lgw_gemm<1><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
         else LG_DISPATCH(s, (void)ITEMS; (k_lg_step1<DMAX><<<gone, kBlock, 0, st>>>(d, k)));
@@ -1939,6 +1960,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     d.lpw = nullptr;
     if (const char* dm = getenv("FBSMI_DEBUG_STEP_MASK")) s->debug_mask = atoi(dm);
     if (const char* gp = getenv("FBSMI_GENERIC_PROP")) s->generic_prop = atoi(gp) != 0;
+    if (const char* sl = getenv("FBSMI_STEP_LAUNCHES")) s->step_launches = atoi(sl) != 0;
     s->items = fbsmi_tile_items(d.N);  // one workgroup = one tile of the two-level logsumexp (include/fbsmi_math.h)
     const int maxd = m->du > m->dv ? m->du : m->dv;
     s->dmax = maxd <= 2 ? 2 : (maxd <= 4 ? 4 : 16);
