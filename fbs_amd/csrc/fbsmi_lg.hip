@@ -1304,6 +1304,142 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     FBSMI_STAMP(24)
 }
 
+// The same product for LARGE wide ensembles: one workgroup keeps its 32 gathered ancestor rows in LDS and
+// walks ALL row tiles of G_s over them (the gather -- the scattered part -- is paid once instead of once
+// per row tile), the next G tile travelling to registers while the matrix cores work on the current one.
+// Ancestors from k_lgw_anc, all rows emitted.  66 KB of LDS: two workgroups per CU, so one's noise draws
+// (VALU) overlap the other's MFMAs.
+__global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nrt, int Kp, int S) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* Gs = dyn;
+    float* Zs = dyn + kWideTile * S;
+    const int N = d.N, du = d.du, D = d.D;
+    const int ts = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t t0 = kt[6], t1 = kt[7];
+    const int j_ref = d.bs[s + 1];
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    const float* __restrict__ G = d.G + (size_t)s * D * D;
+    const float* __restrict__ g = d.g + (size_t)s * D;
+    const float sd = d.sd[s], lognorm = d.lognorm[s];
+    const float sd2 = sd * sd;
+    const float* v_prev = d.vs + (size_t)s * d.dv;
+    const float* v = d.vs + (size_t)(s + 1) * d.dv;
+    const float* ustar = d.us_star + (size_t)(s + 1) * du;
+    constexpr int kRows = kWideTile / kWaves;
+    const bool vec4 = (D & 3) == 0 && (du & 3) == 0;
+    const int Q = Kp >> 2;
+    int an[kRows];
+#pragma unroll
+    for (int jj = 0; jj < kRows; ++jj) {
+        const int mj = kWideTile * ts + wave + kWaves * jj;
+        an[jj] = mj < N ? d.anc[mj] : -1;
+    }
+    float gq[kRows * 4], zq[kRows * 4];
+    auto load_g = [&](int tr) {
+        if (vec4) {
+            const int c = 4 * lane;
+#pragma unroll
+            for (int jj = 0; jj < kRows; ++jj) {
+                const int r = kWideTile * tr + wave + kWaves * jj;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < D && c < D) x = *reinterpret_cast<const float4*>(G + (size_t)r * D + c);
+                gq[jj * 4 + 0] = x.x; gq[jj * 4 + 1] = x.y; gq[jj * 4 + 2] = x.z; gq[jj * 4 + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kRows * 4; ++q) {
+                const int r = kWideTile * tr + wave + kWaves * (q >> 2), c = lane + 64 * (q & 3);
+                gq[q] = (r < D && c < D) ? G[(size_t)r * D + c] : 0.0f;
+            }
+        }
+    };
+    auto store_tile = [&](float* dst, const float (&src)[kRows * 4]) {
+#pragma unroll
+        for (int q = 0; q < kRows * 4; ++q) {
+            const int i = wave + kWaves * (q >> 2);
+            const int c = vec4 ? 4 * lane + (q & 3) : lane + 64 * (q & 3);
+            if (c < Kp) dst[i * S + (c & 3) * Q + (c >> 2)] = src[q];
+        }
+    };
+    load_g(0);
+    if (vec4) {
+        const int c = 4 * lane;
+#pragma unroll
+        for (int jj = 0; jj < kRows; ++jj) {
+            const int a = an[jj];
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a >= 0 && c < D)
+                x = c < du ? *reinterpret_cast<const float4*>(up + (size_t)a * du + c)
+                           : *reinterpret_cast<const float4*>(v_prev + (c - du));
+            zq[jj * 4 + 0] = x.x; zq[jj * 4 + 1] = x.y; zq[jj * 4 + 2] = x.z; zq[jj * 4 + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kRows * 4; ++q) {
+            const int a = an[q >> 2], c = lane + 64 * (q & 3);
+            float z = 0.0f;
+            if (a >= 0 && c < D) z = c < du ? up[(size_t)a * du + c] : v_prev[c - du];
+            zq[q] = z;
+        }
+    }
+    store_tile(Gs, gq);
+    store_tile(Zs, zq);
+    __syncthreads();
+    const int ar = wave >> 1, ac = wave & 1;
+    const int jloc = 16 * ac + (lane & 15);
+    const int mo = kWideTile * ts + jloc;
+    const bool pinned = mo == j_ref;
+    const float4* ga = reinterpret_cast<const float4*>(Gs + (16 * ar + (lane & 15)) * S + (lane >> 4) * Q);
+    const float4* zb = reinterpret_cast<const float4*>(Zs + jloc * S + (lane >> 4) * Q);
+    const int dvp = (d.dv + 3) & ~3;
+#pragma unroll 1
+    for (int tr = 0; tr < nrt; ++tr) {
+        if (tr + 1 < nrt) load_g(tr + 1);   // in flight while this tile is multiplied
+        const int row0 = kWideTile * tr + 16 * ar + 4 * (lane >> 4);
+        mfma_f4 acc;
+        float xi[4];
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) {
+            const int r = row0 + vv;
+            acc[vv] = r < D ? g[r] : 0.0f;
+            xi[vv] = (r < du && mo < N) ? normal_at(t0, t1, (uint64_t)N * du, (uint64_t)mo * du + r) : 0.0f;
+        }
+#pragma unroll 2
+        for (int q4 = 0; q4 < (Q >> 2); ++q4) {
+            const float4 a = ga[q4], b = zb[q4];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+        }
+        if (mo < N) {
+#pragma unroll
+            for (int vv = 0; vv < 4; ++vv) {
+                const int r = row0 + vv;
+                if (r < du) {
+                    float x = (Zs[jloc * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
+                    if (pinned) x = ustar[r];
+                    un[(size_t)mo * du + r] = x;
+                    if (d.uss) d.uss[((size_t)(s + 1) * N + mo) * du + r] = x;
+                } else if (r < D) {
+                    const int rv = r - du;
+                    const float cond_m = v_prev[rv] + acc[vv] * d.dt;
+                    d.lpw[(size_t)mo * dvp + rv] = norm_logpdf(v[rv], cond_m, sd2, lognorm);
+                }
+            }
+        }
+        if (tr + 1 < nrt) {
+            __syncthreads();      // every wave is done reading the G tile
+            store_tile(Gs, gq);
+            __syncthreads();
+        }
+    }
+}
+
 // wide particle filters: initial particles (n, du) row-major -> u0 (same layout) [+ filtering path slot 0]
 __global__ void __launch_bounds__(kBlock) k_lgwf_init(LgDev dd, const float* u0s_all) {
     const LgDev d = chain_view(dd, blockIdx.y);
@@ -1840,7 +1976,10 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
             ProfScope p(s, 2, st);
             if (d.wide) {
                 k_lgw_anc<<<gtile, kBlock, 0, st>>>(d, k);
-                k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
+                if ((int64_t)gwide.x * d.C > 2048)   // enough workgroups to fill the chip twice over: gather once per slot tile
+                    k_lgw_gemm_fat<<<dim3((d.N + kWideTile - 1) / kWideTile, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+                else
+                    k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
                 k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
             } else if (s->items == 1 && !s->generic_prop) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
@@ -2070,6 +2209,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm_fat, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             fbsmi_lg_sweep_destroy(s);
             return fail(FBSMI_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
