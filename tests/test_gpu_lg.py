@@ -121,8 +121,9 @@ WIDE_CASES = [
     (40, 40, 256, 4, True),       # the largest single-launch-per-step ensemble
     (40, 40, 257, 4, True),       # just past it: five launches per step
     (30, 18, 700, 5, False),      # several logsumexp tiles, stored path
-    (20, 20, 40000, 3, True),     # enough workgroups for the fat-tile drift kernel (all row tiles per workgroup)
+    (20, 20, 40000, 3, True),     # enough workgroups for k_lgw_gemm_fat (all row tiles per 32-slot workgroup)
     (33, 17, 35000, 2, False),    # ... with odd sizes and the stored path
+    (100, 100, 12000, 2, True),   # ... at the reference's d = 100 (seven row tiles)
 ]
 
 
