@@ -1329,6 +1329,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     const float* v_prev = d.vs + (size_t)s * d.dv;
     const float* v = d.vs + (size_t)(s + 1) * d.dv;
     const float* ustar = d.us_star + (size_t)(s + 1) * du;
+    FBSMI_STAMP(20)
     constexpr int kRows = kWideTile / kWaves;
     const bool vec4 = (D & 3) == 0 && (du & 3) == 0;
     const int Q = Kp >> 2;
@@ -1389,6 +1390,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     store_tile(Gs, gq);
     store_tile(Zs, zq);
     __syncthreads();
+    FBSMI_STAMP(21)
     const int ar = wave >> 1, ac = wave & 1;
     const int jloc = 16 * ac + (lane & 15);
     const int mo = kWideTile * ts + jloc;
@@ -1416,6 +1418,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
         }
+        if (tr == 0) { FBSMI_STAMP(22) }
+        if (tr == 5) { FBSMI_STAMP(26) }
         if (mo < N) {
 #pragma unroll
             for (int vv = 0; vv < 4; ++vv) {
@@ -1432,12 +1436,17 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
                 }
             }
         }
+        if (tr == 0) { FBSMI_STAMP(23) }
+        if (tr == 5) { FBSMI_STAMP(27) }
         if (tr + 1 < nrt) {
             __syncthreads();      // every wave is done reading the G tile
             store_tile(Gs, gq);
             __syncthreads();
         }
+        if (tr == 0) { FBSMI_STAMP(24) }
+        if (tr == 4) { FBSMI_STAMP(25) }
     }
+    FBSMI_STAMP(30)
 }
 
 // wide particle filters: initial particles (n, du) row-major -> u0 (same layout) [+ filtering path slot 0]

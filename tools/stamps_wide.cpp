@@ -28,6 +28,17 @@ int main(int argc, char** argv) {
     const char* names[32] = {};
     names[25] = "G tile + noise under way, pre in"; names[26] = "pre row sums done"; names[27] = "pre lse known"; names[28] = "pre CDFs in LDS"; names[29] = "pre out";
     names[20] = "gemm in"; names[21] = "gemm ancestor rows landed"; names[22] = "gemm tiles in LDS"; names[23] = "gemm MFMA done"; names[24] = "gemm out";
+    if (N > 256) {   // k_lgw_gemm_fat: entry, tiles staged, tile 0 (MFMA done, epilogue done, G swapped), tile 5 likewise, exit
+        const char* fn[32] = {};
+        fn[20] = "fat in"; fn[21] = "fat G tile 0 + ancestor rows in LDS"; fn[22] = "fat tile 0 MFMA done (noise drawn before)";
+        fn[23] = "fat tile 0 epilogue done"; fn[24] = "fat tile 1 in LDS"; fn[25] = "fat tile 5 in LDS"; fn[26] = "fat tile 5 MFMA done";
+        fn[27] = "fat tile 5 epilogue done"; fn[30] = "fat out";
+        int fo[] = {20, 21, 22, 23, 24, 25, 26, 27, 30};
+        double f0 = rt(20), fp = f0;
+        for (int i : fo) { printf("%-44s t=%8.0f ns  (+%6.0f)\n", fn[i], rt(i) - f0, rt(i) - fp); fp = rt(i); }
+        printf("(d=100, N=%d, chains=%d; the last step of a sweep)\n", N, C);
+        return 0;
+    }
     int order[] = {20, 25, 26, 27, 28, 29, 21, 22, 23, 24};
     double t0 = rt(20), prev = t0;
     for (int i : order) { printf("%-32s t=%8.0f ns  (+%6.0f)\n", names[i], rt(i) - t0, rt(i) - prev); prev = rt(i); }
