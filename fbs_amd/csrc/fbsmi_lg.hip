@@ -1085,19 +1085,22 @@ __device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, 
 // sums -> c = logsumexp -> log-likelihood accumulator -> w -> cumsum -> stratified / systematic ancestors
 // (resampling.py:43-51) with the resampling key of step `kres`.  Call for call the arithmetic of
 // k_lgw_lse -> k_filt_norm<1> -> k_lg_cdf<1,2> -> the search of k_filt_prop with one tile.
-template <typename Early>
+template <bool ROWS, typename Early>
 __device__ __forceinline__ void lgw_fpre_body(const LgDev& d, int kres, bool store, LgwPreLds& L, Early early) {
     const int N = d.N, t = threadIdx.x;
     const uint32_t r0 = d.keytab[8 * kres + 2], r1 = d.keytab[8 * kres + 3];
     const bool live = t < N;
     LgwRowLoads rows;
-    if (live) lgw_row_issue(d, t, rows);
+    float l = 0.0f;
+    if (live) {
+        if (ROWS) lgw_row_issue(d, t, rows);
+        else l = d.lw[t];
+    }
     early();
     float uu = 0.0f;
     if (d.systematic) uu = uniform_at(r0, r1, 1, 0);
     else if (live) uu = uniform_at(r0, r1, (uint64_t)N, (uint64_t)t);
-    float l = 0.0f;
-    if (live) {
+    if (ROWS && live) {
         l = lgw_row_add(d, rows);
         if (store) d.lw[t] = l;
     }
@@ -1216,7 +1219,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     if (KIND == 0 || KIND == 3) draw_noise();
     if (KIND == 1 || KIND == 2) {   // the G tile is on its way; now the step's ancestors, worked out by this workgroup itself
         if (KIND == 1) lgw_pre_body<true>(d, s, blockIdx.x == 0, pre, draw_noise);
-        else lgw_fpre_body(d, kres, blockIdx.x == 0, pre, draw_noise);
+        else lgw_fpre_body<true>(d, kres, blockIdx.x == 0, pre, draw_noise);
 #pragma unroll
         for (int jj = 0; jj < kRows; ++jj) {
             const int mj = kWideTile * ts + wave + kWaves * jj;
@@ -1465,7 +1468,7 @@ __global__ void __launch_bounds__(kBlock) k_lgwf_init(LgDev dd, const float* u0s
 __global__ void __launch_bounds__(kBlock) k_lgwf_final(LgDev dd) {
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ LgwPreLds pre;
-    lgw_fpre_body(d, d.T - 1, true, pre, []() {});
+    lgw_fpre_body<true>(d, d.T - 1, true, pre, []() {});
     const float* __restrict__ up = (d.T & 1) ? d.u1 : d.u0;
     const int tot = d.N * d.du;
     for (int e = threadIdx.x; e < tot; e += kBlock) {
@@ -1537,6 +1540,87 @@ __global__ void __launch_bounds__(kBlock) k_lg_sweep1(LgDev dd) {
     __shared__ LgwPreLds pre;
     for (int s = 0; s < d.T; ++s) {
         lg_step1_body<DMAX>(d, s, pre);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// Narrow particle filters with at most 256 particles: the whole run (bootstrap_filter smc.py:58-86 or
+// pmcmc_filter_step smc.py:138-157) in ONE launch of one workgroup per chain -- per step the filter
+// prologue (logsumexp, log-likelihood accumulator, weights, cumsum, stratified / systematic ancestors, all in
+// LDS) followed by gather, propagate and weight, a workgroup barrier between steps.
+template <int DMAX>
+__global__ void __launch_bounds__(kBlock) k_filt_sweep1(LgDev dd, const float* u0s_all) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ LgwPreLds pre;
+    const int N = d.N, m = threadIdx.x, T = d.T;
+    const bool live = m < N;
+    const float* u0s = u0s_all + (size_t)blockIdx.y * N * d.du;
+    // initial particles; pmcmc: log-weights of step 0 on them (smc.py:144, k = 0)
+    if (live) {
+        float u[DMAX];
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) {
+            u[r] = r < d.du ? u0s[(size_t)m * d.du + r] : 0.0f;
+            if (r < d.du) {
+                d.u0[(size_t)r * N + m] = u[r];
+                if (d.uss) d.uss[(size_t)m * d.du + r] = u[r];
+            }
+        }
+        if (d.flow == 1) d.lw[m] = lg_loglik<DMAX>(step_tables<DMAX>(d, 0), u, d.vs + d.dv, d.vs);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int k = 0; k <= T; ++k) {
+        const bool last = k == T;             // bootstrap only: the final resampling (smc.py:72 of the last step)
+        if (last && d.flow == 1) break;
+        const float* __restrict__ up = (k & 1) ? d.u1 : d.u0;
+        float* __restrict__ un = (k & 1) ? d.u0 : d.u1;
+        const bool resample = d.flow == 1 || k > 0;
+        int a = m;
+        if (resample) {
+            lgw_fpre_body<false>(d, d.flow == 1 ? k : k - 1, true, pre, []() {});
+            a = live ? pre.ancS[m] : 0;
+        }
+        if (live) {
+            float u[DMAX];
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) u[r] = r < d.du ? up[(size_t)r * N + a] : 0.0f;
+            if (last) {
+#pragma unroll
+                for (int r = 0; r < DMAX; ++r)
+                    if (r < d.du) {
+                        d.usT[(size_t)m * d.du + r] = u[r];
+                        if (d.uss) d.uss[((size_t)T * N + m) * d.du + r] = u[r];
+                    }
+            } else {
+                if (d.uss && d.flow == 0 && k > 0) {   // filtering_samples[k] = resampled particles of step k-1
+#pragma unroll
+                    for (int r = 0; r < DMAX; ++r)
+                        if (r < d.du) d.uss[((size_t)k * N + m) * d.du + r] = u[r];
+                }
+                const StepTables<DMAX> t = step_tables<DMAX>(d, k);
+                const uint32_t p0 = d.keytab[8 * k], p1 = d.keytab[8 * k + 1];
+                float x[DMAX];
+#pragma unroll
+                for (int r = 0; r < DMAX; ++r) {
+                    x[r] = 0.0f;
+                    if (r < d.du) {
+                        const float dr = drift_row<DMAX>(t, r, u, d.vs + (size_t)k * d.dv);
+                        const float z = normal_at(p0, p1, (uint64_t)N * d.du, (uint64_t)m * d.du + r);
+                        x[r] = (u[r] + dr * t.dt) + t.sd * z;                 // transition_sampler
+                        un[(size_t)r * N + m] = x[r];
+                        if (k == T - 1 && d.flow == 1) d.usT[(size_t)m * d.du + r] = x[r];
+                    }
+                }
+                if (d.flow == 0) {          // measurement_cond_pdf(v, us_prev, v_prev, t_prev)      smc.py:65
+                    d.lw[m] = lg_loglik<DMAX>(t, u, d.vs + (size_t)(k + 1) * d.dv, d.vs + (size_t)k * d.dv);
+                } else if (k + 1 < T) {     // next step's likelihood_logpdf on the propagated particle  smc.py:144
+                    const StepTables<DMAX> tn = step_tables<DMAX>(d, k + 1);
+                    d.lw[m] = lg_loglik<DMAX>(tn, x, d.vs + (size_t)(k + 2) * d.dv, d.vs + (size_t)(k + 1) * d.dv);
+                }
+            }
+        }
         __threadfence_block();
         __syncthreads();
     }
@@ -2341,6 +2425,12 @@ int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
     const LgDev& d = s->d;
     const dim3 gone(1, d.C), gtile(d.nb, d.C);
     k_filt_keys<<<gone, kBlock, 0, st>>>(d);
+    if (!d.wide && d.N <= kBlock && !s->step_launches) {
+        LG_DISPATCH(s, (void)ITEMS; (k_filt_sweep1<DMAX><<<gone, kBlock, 0, st>>>(d, f->u0s)));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("filter launch: ") + hipGetErrorString(e));
+        return FBSMI_OK;
+    }
     if (d.wide) {
         // one-tile ensembles only (checked at creation): a launch = [filter prologue +] drift product
         const int nrt = (d.D + kWideTile - 1) / kWideTile, Kp = (d.D + 15) / 16 * 16, S = Kp + ((68 - Kp % 64) % 64);

@@ -263,6 +263,7 @@ def test_sharded_module_world1_on_gpu(oracle, dev):
 
 @pytest.mark.parametrize("resampling", ["stratified", "systematic"])
 @pytest.mark.parametrize("toy,n,T", [(toy_2d, 128, 30), (toy_4d, 1000, 12), (toy_2d, 70000, 6),
+                                     (toy_2d, 10, 20), (toy_4d, 256, 8), (toy_4d, 257, 6),   # around the one-launch threshold
                                      (lambda: toy_gp(100), 100, 8),      # the reference's gp_filter / gp_pmcmc scale
                                      (lambda: toy_gp(33, 17), 37, 6),    # wide, odd sizes, tiles straddling du
                                      (lambda: toy_gp(20), 256, 5)])
