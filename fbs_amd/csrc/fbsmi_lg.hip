@@ -19,6 +19,14 @@
 //
 // Particle state is structure-of-arrays u[r][p] so that every per-slot access is coalesced.
 // A whole sweep (3T + ~10 launches) is captured once into a hipGraph and replayed.
+//
+// Variants of the step, chosen at handle creation (all bit-identical to the oracle):
+//   N <= 256 (one logsumexp tile, one workgroup)   : lgw_pre_body does norm + cdf + searches in LDS;
+//       narrow models run the whole T loop in ONE launch (k_lg_sweep1), particle filters too (k_filt_sweep1)
+//   wide models, 16 < max(du, dv) <= 128           : row-major particles, drift on the f32 matrix cores
+//       (k_lgw_gemm: v_mfma_f32_16x16x4_f32 == ascending fmaf chain); N <= 256: one launch per step with the
+//       prologue fused in; N > 256: norm -> cdf -> k_lgw_anc -> k_lgw_gemm | k_lgw_gemm_fat -> k_lgw_lse
+//   N > 131072                                      : 4 / 16 slots per thread (k_lg_prop<ITEMS>)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
