@@ -11,9 +11,10 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SRC = [os.path.join(_HERE, "csrc", n) for n in ("fbsmi_prims.hip", "fbsmi_lg.hip", "fbsmi_sde.hip")]
+_SRC = [os.path.join(_HERE, "csrc", n) for n in ("fbsmi_prims.hip", "fbsmi_lg.hip", "fbsmi_sde.hip", "fbsmi_nn.hip")]
 _DEPS = _SRC + [os.path.join(_HERE, "csrc", "fbsmi_device.h"), os.path.join(_HERE, "csrc", "fbsmi_host.h"),
-                os.path.join(_HERE, "..", "include", "fbsmi.h"), os.path.join(_HERE, "..", "include", "fbsmi_math.h")]
+                os.path.join(_HERE, "..", "include", "fbsmi.h"), os.path.join(_HERE, "..", "include", "fbsmi_math.h"),
+                os.path.join(_HERE, "..", "include", "fbsmi_nn.h")]
 LIB_PATH = os.path.join(_HERE, "lib", "libfbsmi.so")
 
 # -ffp-contract=off is part of the numeric specification (include/fbsmi_math.h)
@@ -91,6 +92,8 @@ SIGNATURES = {
     "fbsmi_lg_filter_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "fbsmi_lg_sweep_profile": (C.c_int, [_vp, C.c_int]),
     "fbsmi_lg_sweep_kernel_us": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    # include/fbsmi_nn.h
+    "fbsmi_nn_linear_attention": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp]),
 }
 
 _lib = None

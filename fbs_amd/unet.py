@@ -141,6 +141,8 @@ class LinearAttention(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
+        if x.is_cuda and self.dim_head == 32 and not torch.is_grad_enabled():
+            return self.to_out_norm(self.to_out(self._fused_core(self.to_qkv(x), B, H, W)))
         q, k, v = self.to_qkv(x).chunk(3, dim=1)
         q, k, v = (t.reshape(B, self.heads, self.dim_head, H * W).permute(0, 3, 1, 2) for t in (q, k, v))  # b n h d
         q = torch.softmax(q, dim=-1)            # over the embedding axis
@@ -151,6 +153,25 @@ class LinearAttention(nn.Module):
         out = torch.einsum('bhde,bnhd->bhen', context, q)                    # (b, h, e, n)
         out = out.reshape(B, self.heads * self.dim_head, H, W)               # channel = (h e)
         return self.to_out_norm(self.to_out(out))
+
+
+def _linear_attention_core(self, qkv, B, H, W):
+    """softmaxes, scalings and both einsums of LinearAttention in one libfbsmi kernel (inference, on the GPU)."""
+    import ctypes
+    from . import _lib
+    dt = {torch.float32: 0, torch.bfloat16: 1}.get(qkv.dtype)
+    if dt is None:
+        qkv, dt = qkv.float(), 0
+    tok = qkv.permute(0, 2, 3, 1).contiguous()          # (B, H, W, 3hd): free for a channels_last convolution output
+    out = torch.empty((B, H, W, self.heads * self.dim_head), dtype=tok.dtype, device=tok.device)
+    for b0 in range(0, B, 32768):
+        nb = min(32768, B - b0)
+        _lib.call("fbsmi_nn_linear_attention", tok[b0:b0 + nb].data_ptr(), out[b0:b0 + nb].data_ptr(), dt, nb, H * W,
+                  self.heads, self.dim_head, torch.cuda.current_stream().cuda_stream)
+    return out.permute(0, 3, 1, 2)                     # NCHW view, channel = (head, e)
+
+
+LinearAttention._fused_core = _linear_attention_core
 
 
 class AttnBlock(nn.Module):

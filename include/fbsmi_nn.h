@@ -1,0 +1,25 @@
+/* fbsmi_nn.h -- device kernels for the score network of the image experiments (SURVEY.md section 8 f1:
+ * the flax UNet of fbs/nn/unet.py restated in torch, fbs_amd/unet.py).  Not part of the sampler hot
+ * path (include/fbsmi.h); same conventions: extern "C", device pointers, int status, void* stream. */
+#ifndef FBSMI_NN_H
+#define FBSMI_NN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* LinearAttention core of fbs/nn/unet.py:209-245 for dim_head = 32:
+ *   q = softmax(q, over the embedding) / sqrt(dim_head);  k = softmax(k, over the tokens);  v = v / n
+ *   context[d][e] = sum_n k[n][d] v[n][e];   out[n][e] = sum_d context[d][e] q[n][d]
+ * qkv: (B, n, 3 * heads * 32) token-major (a channels_last (B, 3hd, H, W) convolution output viewed as
+ * (B, H*W, 3hd)); channel = which * heads * 32 + head * 32 + d, which = 0 q, 1 k, 2 v.
+ * out: (B, n, heads * 32), channel = head * 32 + e.  dtype: 0 float32, 1 bfloat16 (computed in float32). */
+int fbsmi_nn_linear_attention(const void* qkv, void* out, int dtype, int64_t B, int32_t n, int32_t heads,
+                              int32_t dim_head, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library loads and exports every symbol include/fbsmi.h declares; host-side logic
+"""CPU: the C-ABI library loads and exports every symbol include/fbsmi.h (and fbsmi_nn.h) declares; host-side logic
 (key splitting, SDE coefficients, table builder) agrees with the oracle / closed forms; the product
 refuses to run without a GPU instead of falling back."""
 import ctypes
@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_functions():
-    text = open(os.path.join(ROOT, "include", "fbsmi.h")).read()
+    text = open(os.path.join(ROOT, "include", "fbsmi.h")).read() + open(os.path.join(ROOT, "include", "fbsmi_nn.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(fbsmi_[a-z0-9_]+)\s*\(", text)))
 

@@ -99,3 +99,28 @@ def test_unet_reference_configuration_size():
     assert 5_000_000 < n < 20_000_000
     _, _, fwd = make_st_nn(net)
     assert fwd(torch.zeros(2, 28, 28, 1), 0.3).shape == (2, 28, 28, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,dim", [(5, 28, 28, 64), (3, 7, 7, 256), (2, 9, 13, 128), (1, 64, 64, 64)])
+def test_fused_linear_attention_matches_the_torch_ops(B, H, W, dim):
+    """libfbsmi's one-kernel LinearAttention core (include/fbsmi_nn.h) against the eager restatement of
+    fbs/nn/unet.py:209-245 in fbs_amd/unet.py, float32 (tight) and bfloat16 autocast (bf16 tolerance)."""
+    from fbs_amd.unet import LinearAttention
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B * 100 + H)
+    attn = LinearAttention(dim).to(dev).eval()
+    x = torch.randn(B, dim, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.enable_grad():          # autograd on: the eager path
+        want = attn(x).detach()
+    with torch.no_grad():              # inference: the fused kernel
+        got = attn(x)
+    assert got.shape == want.shape
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-5 * max(scale, 1.0)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.enable_grad():
+            want16 = attn(x).detach().float()
+        with torch.no_grad():
+            got16 = attn(x).float()
+    assert (got16 - want16).abs().max().item() <= 3e-2 * max(want16.abs().max().item(), 1.0)
