@@ -134,6 +134,123 @@ __global__ void __launch_bounds__(256) k_linear_attention(const T* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// GroupNorm + modulation + SiLU.  One workgroup per image; a thread owns one aligned 8-channel vector slot
+// (always inside one group, since the group size is a multiple of 8) across a strided set of tokens:
+// pass 1 Welford-merges its vectors into (count, mean, M2), the slots of a group are merged through LDS
+// (Chan's formula); pass 2 re-reads (L2-hot), normalises, modulates, applies SiLU and stores.
+// ------------------------------------------------------------------------------------------
+struct Vec8 {
+    float v[8];
+};
+__device__ __forceinline__ Vec8 ld8(const float* p) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    return Vec8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ Vec8 ld8(const __hip_bfloat16* p) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+    Vec8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o.v[2 * i] = __uint_as_float(w[i] << 16);
+        o.v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    }
+    return o;
+}
+__device__ __forceinline__ void st8(float* p, const Vec8& x) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+__device__ __forceinline__ void st8(__hip_bfloat16* p, const Vec8& x) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __hip_bfloat16 lo = __float2bfloat16(x.v[2 * i]), hi = __float2bfloat16(x.v[2 * i + 1]);
+        w[i] = (unsigned)(*reinterpret_cast<const unsigned short*>(&lo)) |
+               ((unsigned)(*reinterpret_cast<const unsigned short*>(&hi)) << 16);
+    }
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x, T* __restrict__ y, int n, int C, int groups,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int slots = C >> 3;                 // 8-channel vector slots per token (<= 256 / 8 ... C <= 2048)
+    const int spg = slots / groups;           // slots per group
+    const int lanes = 256 / slots;            // token lanes (slots divides 256: C in {64, 128, 256, 512, ...})
+    const int slot = t % slots, tl = t / slots;
+    const T* xb = x + (size_t)b * n * C + slot * 8;
+    T* yb = y + (size_t)b * n * C + slot * 8;
+    __shared__ float sN[256], sMean[256], sM2[256];
+    __shared__ float gMean[32], gRstd[32];
+    // ---- pass 1
+    float cnt = 0.0f, mean = 0.0f, M2 = 0.0f;
+    if (tl < lanes) {
+        for (int tok = tl; tok < n; tok += lanes) {
+            const Vec8 v = ld8(xb + (size_t)tok * C);
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v.v[i];
+            const float m8 = s * 0.125f;
+            float q = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q += (v.v[i] - m8) * (v.v[i] - m8);
+            const float nn = cnt + 8.0f, dlt = m8 - mean;
+            mean += dlt * (8.0f / nn);
+            M2 += q + dlt * dlt * (cnt * 8.0f / nn);
+            cnt = nn;
+        }
+    }
+    sN[t] = cnt;
+    sMean[t] = mean;
+    sM2[t] = M2;
+    __syncthreads();
+    if (t < groups) {
+        float N = 0.0f, Mn = 0.0f, Mq = 0.0f;
+        for (int l = 0; l < lanes; ++l)
+            for (int sIdx = t * spg; sIdx < (t + 1) * spg; ++sIdx) {
+                const int j = l * slots + sIdx;
+                const float nb = sN[j];
+                if (nb > 0.0f) {
+                    const float nt = N + nb, dlt = sMean[j] - Mn;
+                    Mn += dlt * (nb / nt);
+                    Mq += sM2[j] + dlt * dlt * (N * nb / nt);
+                    N = nt;
+                }
+            }
+        gMean[t] = Mn;
+        gRstd[t] = rsqrtf(Mq / N + eps);
+    }
+    __syncthreads();
+    // ---- pass 2
+    if (tl < lanes) {
+        const int g = slot / spg;
+        const float mu = gMean[g], rs = gRstd[g];
+        float a[8], c[8];   // y = silu(x * a + c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = slot * 8 + i;
+            const float ga = gamma[ch] * rs, be = beta[ch] - mu * ga;
+            const float sc = scale ? 1.0f + scale[(size_t)b * C + ch] : 1.0f, sh = shift ? shift[(size_t)b * C + ch] : 0.0f;
+            a[i] = ga * sc;
+            c[i] = be * sc + sh;
+        }
+        for (int tok = tl; tok < n; tok += lanes) {
+            Vec8 v = ld8(xb + (size_t)tok * C);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float z = fmaf(v.v[i], a[i], c[i]);
+                v.v[i] = z / (1.0f + expf(-z));
+            }
+            st8(yb + (size_t)tok * C, v);
+        }
+    }
+}
+
 }  // namespace fbsmi
 
 using namespace fbsmi;
@@ -151,6 +268,28 @@ extern "C" int fbsmi_nn_linear_attention(const void* qkv, void* out, int dtype, 
     else
         k_linear_attention<__hip_bfloat16><<<grid, 256, 0, (hipStream_t)stream>>>((const __hip_bfloat16*)qkv,
                                                                                  (__hip_bfloat16*)out, n, heads);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
+    return FBSMI_OK;
+}
+
+extern "C" int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_t B, int32_t n, int32_t C, int32_t groups,
+                                       const float* gamma, const float* beta, float eps, const float* scale,
+                                       const float* shift, void* stream) {
+    if (!x || !y || !gamma || !beta || B < 0 || n < 1 || C < 8 || groups < 1 || groups > 32 || (dtype != 0 && dtype != 1) ||
+        (scale == nullptr) != (shift == nullptr))
+        return fail(FBSMI_ERR_ARG, "nn_groupnorm_silu: bad arguments");
+    const int slots = C / 8;
+    if (C % (8 * groups) != 0 || slots > 256 || 256 % slots != 0)
+        return fail(FBSMI_ERR_UNSUPPORTED, "nn_groupnorm_silu: C must be a multiple of 8 * groups and C / 8 must divide 256");
+    if (B == 0) return FBSMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        k_groupnorm_silu<float><<<(unsigned)B, 256, 0, st>>>((const float*)x, (float*)y, n, C, groups, gamma, beta, eps,
+                                                            scale, shift);
+    else
+        k_groupnorm_silu<__hip_bfloat16><<<(unsigned)B, 256, 0, st>>>((const __hip_bfloat16*)x, (__hip_bfloat16*)y, n, C,
+                                                                     groups, gamma, beta, eps, scale, shift);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
     return FBSMI_OK;

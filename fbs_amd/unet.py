@@ -60,6 +60,8 @@ class _ChannelLayerNorm(nn.Module):
         self.eps = eps
 
     def forward(self, x):
+        if x.is_cuda:   # one layer_norm kernel over the channel axis of the channels_last view
+            return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), self.scale, None, self.eps).permute(0, 3, 1, 2)
         mean = x.mean(dim=1, keepdim=True)
         var = x.var(dim=1, unbiased=False, keepdim=True)
         return (x - mean) * torch.rsqrt(var + self.eps) * self.scale.view(1, -1, 1, 1)
@@ -80,6 +82,35 @@ class WeightStandardizedConv(nn.Module):
         return F.conv2d(x, w, self.conv.bias, padding=self.conv.padding)
 
 
+def _nchw_view(tok):
+    """(B, H, W, C) token-major -> NCHW.  bfloat16 stays channels_last (MIOpen's NHWC kernels, the fast path);
+    float32 is copied to NCHW-contiguous: MIOpen's float32 NHWC convolutions accumulate with atomics and are not
+    reproducible run to run, which a sampler with explicit keys must be."""
+    out = tok.permute(0, 3, 1, 2)
+    return out.contiguous() if tok.dtype == torch.float32 else out
+
+
+def _gn_fusable(norm: nn.GroupNorm) -> bool:
+    C, g = norm.num_channels, norm.num_groups
+    return C % (8 * g) == 0 and g <= 32 and (C // 8) <= 256 and 256 % (C // 8) == 0
+
+
+def _gn_silu(x, norm: nn.GroupNorm, scale, shift):
+    """silu(GroupNorm(x) * (1 + scale) + shift) in one libfbsmi kernel (include/fbsmi_nn.h); x is NCHW (any strides)."""
+    from . import _lib
+    dt = {torch.float32: 0, torch.bfloat16: 1}.get(x.dtype)
+    if dt is None:
+        x, dt = x.float(), 0
+    B, C, H, W = x.shape
+    tok = x.permute(0, 2, 3, 1).contiguous()            # free for channels_last activations
+    out = torch.empty_like(tok)
+    _lib.call("fbsmi_nn_groupnorm_silu", tok.data_ptr(), out.data_ptr(), dt, B, H * W, C, norm.num_groups,
+              norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
+              scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None,
+              torch.cuda.current_stream().cuda_stream)
+    return _nchw_view(out)
+
+
 class ResnetBlock(nn.Module):
     """fbs/nn/unet.py:127-172."""
 
@@ -93,6 +124,15 @@ class ResnetBlock(nn.Module):
         self.res_conv = nn.Conv2d(dim_in, dim, 1) if dim_in != dim else None
 
     def forward(self, x, time_emb):
+        if x.is_cuda and not torch.is_grad_enabled() and _gn_fusable(self.norm_0):
+            te = self.time_mlp(F.silu(time_emb)).float()
+            B = x.shape[0]
+            scale, shift = (p.expand(B, p.shape[1]).contiguous() for p in te.chunk(2, dim=1))
+            h = _gn_silu(self.conv_0(x), self.norm_0, scale, shift)
+            h = _gn_silu(self.conv_1(h), self.norm_1, None, None)
+            if self.res_conv is not None:
+                x = self.res_conv(x)
+            return x + h
         h = self.norm_0(self.conv_0(x))
         te = self.time_mlp(F.silu(time_emb))[:, :, None, None]
         scale, shift = te.chunk(2, dim=1)
@@ -168,7 +208,7 @@ def _linear_attention_core(self, qkv, B, H, W):
         nb = min(32768, B - b0)
         _lib.call("fbsmi_nn_linear_attention", tok[b0:b0 + nb].data_ptr(), out[b0:b0 + nb].data_ptr(), dt, nb, H * W,
                   self.heads, self.dim_head, torch.cuda.current_stream().cuda_stream)
-    return out.permute(0, 3, 1, 2)                     # NCHW view, channel = (head, e)
+    return _nchw_view(out)                             # NCHW view, channel = (head, e)
 
 
 LinearAttention._fused_core = _linear_attention_core

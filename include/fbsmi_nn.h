@@ -19,6 +19,16 @@ extern "C" {
 int fbsmi_nn_linear_attention(const void* qkv, void* out, int dtype, int64_t B, int32_t n, int32_t heads,
                               int32_t dim_head, void* stream);
 
+/* GroupNorm (biased variance, eps) + per-image channel modulation + SiLU in one pass over the activations --
+ * the two normalisation sites of ResnetBlock (fbs/nn/unet.py:127-172):
+ *   y = silu( ((x - mean_g) * rsqrt(var_g + eps) * gamma[c] + beta[c]) * (1 + scale[b][c]) + shift[b][c] )
+ * x, y: (B, n, C) token-major (channels_last); C a multiple of 8 * groups; gamma, beta: (C) float32;
+ * scale, shift: (B, C) float32 or NULL (no modulation).  dtype: 0 float32, 1 bfloat16 (statistics in float32,
+ * Welford / Chan merging). */
+int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_t B, int32_t n, int32_t C, int32_t groups,
+                            const float* gamma, const float* beta, float eps, const float* scale, const float* shift,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,3 +124,36 @@ def test_fused_linear_attention_matches_the_torch_ops(B, H, W, dim):
         with torch.no_grad():
             got16 = attn(x).float()
     assert (got16 - want16).abs().max().item() <= 3e-2 * max(want16.abs().max().item(), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,din,dim", [(6, 28, 28, 64, 64), (3, 14, 14, 64, 128), (2, 7, 7, 384, 256), (1, 64, 64, 128, 64)])
+def test_fused_resnet_block_matches_the_torch_ops(B, H, W, din, dim):
+    """ResnetBlock with libfbsmi's GroupNorm + modulation + SiLU kernel against the eager restatement of
+    fbs/nn/unet.py:127-172, float32 and bfloat16 autocast; the same for the channel LayerNorm's fused path."""
+    from fbs_amd.unet import ResnetBlock, _ChannelLayerNorm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(dim + H)
+    blk = ResnetBlock(din, dim, 256).to(dev).eval()
+    with torch.no_grad():
+        for nrm in (blk.norm_0, blk.norm_1):
+            nrm.weight.uniform_(0.5, 1.5)
+            nrm.bias.uniform_(-0.3, 0.3)
+    x = (torch.randn(B, din, H, W, device=dev) * 2 + 0.7).contiguous(memory_format=torch.channels_last)
+    emb = torch.randn(B, 256, device=dev)
+    with torch.enable_grad():
+        want = blk(x, emb).detach()
+    with torch.no_grad():
+        got = blk(x, emb)
+    assert (got - want).abs().max().item() <= 1e-4 * max(want.abs().max().item(), 1.0)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.enable_grad():
+            want16 = blk(x, emb).detach().float()
+        with torch.no_grad():
+            got16 = blk(x, emb).float()
+    assert (got16 - want16).abs().max().item() <= 4e-2 * max(want16.abs().max().item(), 1.0)
+    ln = _ChannelLayerNorm(din).to(dev)
+    with torch.no_grad():
+        ln.scale.uniform_(0.5, 1.5)
+    ref = (x - x.mean(1, keepdim=True)) * torch.rsqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5) * ln.scale.view(1, -1, 1, 1)
+    assert (ln(x) - ref).abs().max().item() <= 1e-4
