@@ -251,6 +251,39 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Channel LayerNorm: a row of C channels is C / 8 adjacent lanes (one 16-byte vector each), reductions by
+// xor-shuffles inside that lane group; one read, one write.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_channel_layernorm(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int C,
+                                                           const float* __restrict__ scale, float eps) {
+    const int L = C >> 3;                                   // lanes per row (power of two, <= 64)
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / L;
+    const int slot = threadIdx.x % L;
+    const bool live = row < rows;
+    Vec8 v;
+    if (live) v = ld8(x + row * C + slot * 8);
+    else
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v.v[i] = 0.0f;
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v.v[i];
+    for (int m = 1; m < L; m <<= 1) s += __shfl_xor(s, m);
+    const float mean = s / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q += (v.v[i] - mean) * (v.v[i] - mean);
+    for (int m = 1; m < L; m <<= 1) q += __shfl_xor(q, m);
+    const float rs = rsqrtf(q / (float)C + eps);
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v.v[i] = (v.v[i] - mean) * rs * scale[slot * 8 + i];
+        st8(y + row * C + slot * 8, v);
+    }
+}
+
 }  // namespace fbsmi
 
 using namespace fbsmi;
@@ -290,6 +323,28 @@ extern "C" int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_
     else
         k_groupnorm_silu<__hip_bfloat16><<<(unsigned)B, 256, 0, st>>>((const __hip_bfloat16*)x, (__hip_bfloat16*)y, n, C,
                                                                      groups, gamma, beta, eps, scale, shift);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
+    return FBSMI_OK;
+}
+
+extern "C" int fbsmi_nn_channel_layernorm(const void* x, void* y, int dtype, int64_t rows, int32_t C, const float* scale,
+                                          float eps, void* stream) {
+    if (!x || !y || !scale || rows < 0 || C < 8 || (dtype != 0 && dtype != 1))
+        return fail(FBSMI_ERR_ARG, "nn_channel_layernorm: bad arguments");
+    const int L = C / 8;
+    if (C % 8 != 0 || L > 64 || (L & (L - 1)) != 0)
+        return fail(FBSMI_ERR_UNSUPPORTED, "nn_channel_layernorm: C / 8 must be a power of two <= 64");
+    if (rows == 0) return FBSMI_OK;
+    const int64_t per_block = 256 / L;
+    const int64_t blocks = (rows + per_block - 1) / per_block;
+    if (blocks > 0x7fffffff) return fail(FBSMI_ERR_UNSUPPORTED, "nn_channel_layernorm: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        k_channel_layernorm<float><<<(unsigned)blocks, 256, 0, st>>>((const float*)x, (float*)y, rows, C, scale, eps);
+    else
+        k_channel_layernorm<__hip_bfloat16><<<(unsigned)blocks, 256, 0, st>>>((const __hip_bfloat16*)x, (__hip_bfloat16*)y,
+                                                                             rows, C, scale, eps);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
     return FBSMI_OK;

@@ -29,6 +29,13 @@ int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_t B, int32_
                             const float* gamma, const float* beta, float eps, const float* scale, const float* shift,
                             void* stream);
 
+/* LayerNorm over the channel axis without bias (flax nn.LayerNorm(epsilon, use_bias=False), fbs/nn/unet.py:
+ * the PreNorm of every attention block and LinearAttention's output norm):
+ *   y[r][c] = (x[r][c] - mean_r) * rsqrt(var_r + eps) * scale[c],  biased variance over the C channels of row r.
+ * x, y: (rows, C) with C / 8 a power of two <= 64; dtype 0 float32, 1 bfloat16 (statistics in float32). */
+int fbsmi_nn_channel_layernorm(const void* x, void* y, int dtype, int64_t rows, int32_t C, const float* scale, float eps,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif
