@@ -85,12 +85,26 @@ class WeightStandardizedConv(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(dim_in, features, kernel_size, padding=padding)
 
-    def forward(self, x):
+    def _standardised(self):
         w = self.conv.weight                      # (out, in, kh, kw): statistics per output channel
         mean = w.mean(dim=(1, 2, 3), keepdim=True)
         var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
-        w = (w - mean) / torch.sqrt(var + 1e-5)
-        return F.conv2d(x, w, self.conv.bias, padding=self.conv.padding)
+        return (w - mean) / torch.sqrt(var + 1e-5)
+
+    def forward(self, x):
+        if torch.is_grad_enabled() or self.training:
+            return F.conv2d(x, self._standardised(), self.conv.bias, padding=self.conv.padding)
+        # inference: the weights are constants, standardise them once (per weight version, device and compute dtype)
+        w0 = self.conv.weight
+        dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled()) else w0.dtype
+        tag = (w0._version, w0.data_ptr(), w0.device, dt)
+        if getattr(self, "_w_tag", None) != tag:
+            with torch.no_grad():
+                w = self._standardised().to(dt)
+                if x.is_cuda and dt != torch.float32:
+                    w = w.contiguous(memory_format=torch.channels_last)
+            self._w_std, self._w_tag = w, tag
+        return F.conv2d(x, self._w_std, self.conv.bias, padding=self.conv.padding)
 
 
 def _nchw_view(tok):
@@ -321,6 +335,8 @@ class UNet(nn.Module):
             x = x.unsqueeze(0)
         B = x.shape[0]
         h = self.init_conv(x.permute(0, 3, 1, 2))      # NHWC -> NCHW view (channels_last strides)
+        if h.is_cuda and h.dtype != torch.float32 and not torch.is_grad_enabled():
+            h = h.contiguous(memory_format=torch.channels_last)   # the whole bf16 network then stays NHWC (MIOpen's fast path)
         hs = [h]
         time = torch.as_tensor(time, dtype=torch.float32, device=x.device)
         emb = sinusoidal_embedding(time / self.dt, out_dim=self.dim)
