@@ -137,3 +137,19 @@ def test_table_builder_matches_reference_closures(toy, oracle):
             score = -np.linalg.solve(cov, z - Ft * toy["m0"])
             want = -osde["a"](t_fwd) * z + osde["b"](t_fwd) ** 2 * score
             np.testing.assert_allclose(tab["G"][k] @ z + tab["g"][k], want, rtol=1e-10)
+
+
+def test_nn_kernels_refuse_unsupported_shapes_loudly():
+    """include/fbsmi_nn.h: shape checks run on the host before any launch (no GPU needed to see them)."""
+    from fbs_amd import _lib
+    p = 4096   # never dereferenced: every call below fails its argument check first
+    with pytest.raises(NotImplementedError):
+        _lib.call("fbsmi_nn_linear_attention", p, p, 0, 1, 16, 4, 16, None)          # dim_head != 32
+    with pytest.raises(NotImplementedError):
+        _lib.call("fbsmi_nn_groupnorm_silu", p, p, 0, 1, 16, 12, 8, p, p, 1e-6, None, None, None)   # C % (8 * groups)
+    with pytest.raises(NotImplementedError):
+        _lib.call("fbsmi_nn_channel_layernorm", p, p, 1, 10, 24, p, 1e-5, None)      # C / 8 = 3 is not a power of two
+    with pytest.raises(RuntimeError):
+        _lib.call("fbsmi_nn_linear_attention", None, p, 0, 1, 16, 4, 32, None)       # null input
+    with pytest.raises(RuntimeError):
+        _lib.call("fbsmi_nn_groupnorm_silu", p, p, 2, 1, 16, 64, 8, p, p, 1e-6, None, None, None)   # unknown dtype
