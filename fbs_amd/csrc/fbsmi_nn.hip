@@ -177,7 +177,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x, T* __restrict__ y, int n, int C, int groups,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift) {
+                                                        const float* __restrict__ shift, const float* __restrict__ xbias) {
     const int b = blockIdx.x, t = threadIdx.x;
     const int slots = C >> 3;                 // 8-channel vector slots per token (<= 256 / 8 ... C <= 2048)
     const int spg = slots / groups;           // slots per group
@@ -187,11 +187,16 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
     T* yb = y + (size_t)b * n * C + slot * 8;
     __shared__ float sN[256], sMean[256], sM2[256];
     __shared__ float gMean[32], gRstd[32];
+    float xb8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xb8[i] = xbias ? xbias[slot * 8 + i] : 0.0f;
     // ---- pass 1
     float cnt = 0.0f, mean = 0.0f, M2 = 0.0f;
     if (tl < lanes) {
         for (int tok = tl; tok < n; tok += lanes) {
-            const Vec8 v = ld8(xb + (size_t)tok * C);
+            Vec8 v = ld8(xb + (size_t)tok * C);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v.v[i] += xb8[i];
             float s = 0.0f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) s += v.v[i];
@@ -237,7 +242,7 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
             const float ga = gamma[ch] * rs, be = beta[ch] - mu * ga;
             const float sc = scale ? 1.0f + scale[(size_t)b * C + ch] : 1.0f, sh = shift ? shift[(size_t)b * C + ch] : 0.0f;
             a[i] = ga * sc;
-            c[i] = be * sc + sh;
+            c[i] = fmaf(xb8[i], a[i], be * sc + sh);   // (x + xbias) * a + c0
         }
         for (int tok = tl; tok < n; tok += lanes) {
             Vec8 v = ld8(xb + (size_t)tok * C);
@@ -308,7 +313,7 @@ extern "C" int fbsmi_nn_linear_attention(const void* qkv, void* out, int dtype, 
 
 extern "C" int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_t B, int32_t n, int32_t C, int32_t groups,
                                        const float* gamma, const float* beta, float eps, const float* scale,
-                                       const float* shift, void* stream) {
+                                       const float* shift, const float* xbias, void* stream) {
     if (!x || !y || !gamma || !beta || B < 0 || n < 1 || C < 8 || groups < 1 || groups > 32 || (dtype != 0 && dtype != 1) ||
         (scale == nullptr) != (shift == nullptr))
         return fail(FBSMI_ERR_ARG, "nn_groupnorm_silu: bad arguments");
@@ -319,10 +324,10 @@ extern "C" int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
         k_groupnorm_silu<float><<<(unsigned)B, 256, 0, st>>>((const float*)x, (float*)y, n, C, groups, gamma, beta, eps,
-                                                            scale, shift);
+                                                            scale, shift, xbias);
     else
         k_groupnorm_silu<__hip_bfloat16><<<(unsigned)B, 256, 0, st>>>((const __hip_bfloat16*)x, (__hip_bfloat16*)y, n, C,
-                                                                     groups, gamma, beta, eps, scale, shift);
+                                                                     groups, gamma, beta, eps, scale, shift, xbias);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
     return FBSMI_OK;
