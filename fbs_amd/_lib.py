@@ -94,8 +94,8 @@ SIGNATURES = {
     "fbsmi_lg_sweep_kernel_us": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
     # include/fbsmi_nn.h
     "fbsmi_nn_linear_attention": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp]),
-    "fbsmi_nn_channel_layernorm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _vp, _f, _vp]),
-    "fbsmi_nn_groupnorm_silu": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "fbsmi_nn_channel_layernorm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _vp, _f, _vp, _vp]),
+    "fbsmi_nn_groupnorm_silu": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

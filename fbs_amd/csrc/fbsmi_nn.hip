@@ -177,7 +177,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x, T* __restrict__ y, int n, int C, int groups,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, const float* __restrict__ xbias) {
+                                                        const float* __restrict__ shift, const float* __restrict__ xbias,
+                                                        const T* __restrict__ residual) {
     const int b = blockIdx.x, t = threadIdx.x;
     const int slots = C >> 3;                 // 8-channel vector slots per token (<= 256 / 8 ... C <= 2048)
     const int spg = slots / groups;           // slots per group
@@ -244,12 +245,18 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
             a[i] = ga * sc;
             c[i] = fmaf(xb8[i], a[i], be * sc + sh);   // (x + xbias) * a + c0
         }
+        const T* rb = residual ? residual + (size_t)b * n * C + slot * 8 : nullptr;
         for (int tok = tl; tok < n; tok += lanes) {
             Vec8 v = ld8(xb + (size_t)tok * C);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float z = fmaf(v.v[i], a[i], c[i]);
                 v.v[i] = z / (1.0f + expf(-z));
+            }
+            if (rb) {
+                const Vec8 r = ld8(rb + (size_t)tok * C);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
             }
             st8(yb + (size_t)tok * C, v);
         }
@@ -262,7 +269,8 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) k_channel_layernorm(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int C,
-                                                           const float* __restrict__ scale, float eps) {
+                                                           const float* __restrict__ scale, float eps,
+                                                           const T* __restrict__ residual) {
     const int L = C >> 3;                                   // lanes per row (power of two, <= 64)
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / L;
     const int slot = threadIdx.x % L;
@@ -285,6 +293,11 @@ __global__ void __launch_bounds__(256) k_channel_layernorm(const T* __restrict__
     if (live) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v.v[i] = (v.v[i] - mean) * rs * scale[slot * 8 + i];
+        if (residual) {
+            const Vec8 r = ld8(residual + row * C + slot * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
+        }
         st8(y + row * C + slot * 8, v);
     }
 }
@@ -313,7 +326,7 @@ extern "C" int fbsmi_nn_linear_attention(const void* qkv, void* out, int dtype, 
 
 extern "C" int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_t B, int32_t n, int32_t C, int32_t groups,
                                        const float* gamma, const float* beta, float eps, const float* scale,
-                                       const float* shift, const float* xbias, void* stream) {
+                                       const float* shift, const float* xbias, const void* residual, void* stream) {
     if (!x || !y || !gamma || !beta || B < 0 || n < 1 || C < 8 || groups < 1 || groups > 32 || (dtype != 0 && dtype != 1) ||
         (scale == nullptr) != (shift == nullptr))
         return fail(FBSMI_ERR_ARG, "nn_groupnorm_silu: bad arguments");
@@ -324,17 +337,18 @@ extern "C" int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
         k_groupnorm_silu<float><<<(unsigned)B, 256, 0, st>>>((const float*)x, (float*)y, n, C, groups, gamma, beta, eps,
-                                                            scale, shift, xbias);
+                                                            scale, shift, xbias, (const float*)residual);
     else
         k_groupnorm_silu<__hip_bfloat16><<<(unsigned)B, 256, 0, st>>>((const __hip_bfloat16*)x, (__hip_bfloat16*)y, n, C,
-                                                                     groups, gamma, beta, eps, scale, shift, xbias);
+                                                                     groups, gamma, beta, eps, scale, shift, xbias,
+                                                                     (const __hip_bfloat16*)residual);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
     return FBSMI_OK;
 }
 
 extern "C" int fbsmi_nn_channel_layernorm(const void* x, void* y, int dtype, int64_t rows, int32_t C, const float* scale,
-                                          float eps, void* stream) {
+                                          float eps, const void* residual, void* stream) {
     if (!x || !y || !scale || rows < 0 || C < 8 || (dtype != 0 && dtype != 1))
         return fail(FBSMI_ERR_ARG, "nn_channel_layernorm: bad arguments");
     const int L = C / 8;
@@ -346,10 +360,11 @@ extern "C" int fbsmi_nn_channel_layernorm(const void* x, void* y, int dtype, int
     if (blocks > 0x7fffffff) return fail(FBSMI_ERR_UNSUPPORTED, "nn_channel_layernorm: too many rows");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
-        k_channel_layernorm<float><<<(unsigned)blocks, 256, 0, st>>>((const float*)x, (float*)y, rows, C, scale, eps);
+        k_channel_layernorm<float><<<(unsigned)blocks, 256, 0, st>>>((const float*)x, (float*)y, rows, C, scale, eps,
+                                                                     (const float*)residual);
     else
         k_channel_layernorm<__hip_bfloat16><<<(unsigned)blocks, 256, 0, st>>>((const __hip_bfloat16*)x, (__hip_bfloat16*)y,
-                                                                             rows, C, scale, eps);
+                                                                             rows, C, scale, eps, (const __hip_bfloat16*)residual);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
     return FBSMI_OK;

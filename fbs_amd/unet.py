@@ -59,18 +59,27 @@ class _ChannelLayerNorm(nn.Module):
         self.scale = nn.Parameter(torch.ones(dim))
         self.eps = eps
 
-    def forward(self, x):
+    def fusable(self, x) -> bool:
         C = x.shape[1]
-        if x.is_cuda and not torch.is_grad_enabled() and C % 8 == 0 and (C // 8) <= 64 and ((C // 8) & (C // 8 - 1)) == 0:
+        return x.is_cuda and not torch.is_grad_enabled() and C % 8 == 0 and (C // 8) <= 64 and ((C // 8) & (C // 8 - 1)) == 0
+
+    def forward(self, x, residual=None):
+        """LayerNorm over channels [+ residual: the attention block's skip connection, added in the same kernel]."""
+        C = x.shape[1]
+        if self.fusable(x):
             from . import _lib
             dt = {torch.float32: 0, torch.bfloat16: 1}.get(x.dtype)
             if dt is None:
                 x, dt = x.float(), 0
             tok = x.permute(0, 2, 3, 1).contiguous()
+            res = residual.to(tok.dtype).permute(0, 2, 3, 1).contiguous() if residual is not None else None
             out = torch.empty_like(tok)
             _lib.call("fbsmi_nn_channel_layernorm", tok.data_ptr(), out.data_ptr(), dt, tok.numel() // C, C,
-                      self.scale.data_ptr(), float(self.eps), torch.cuda.current_stream().cuda_stream)
+                      self.scale.data_ptr(), float(self.eps), res.data_ptr() if res is not None else None,
+                      torch.cuda.current_stream().cuda_stream)
             return _nchw_view(out)
+        if residual is not None:
+            return self.forward(x) + residual
         if x.is_cuda:   # one layer_norm kernel over the channel axis of the channels_last view
             return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), self.scale, None, self.eps).permute(0, 3, 1, 2)
         mean = x.mean(dim=1, keepdim=True)
@@ -121,20 +130,27 @@ def _gn_fusable(norm: nn.GroupNorm) -> bool:
     return C % (8 * g) == 0 and g <= 32 and (C // 8) <= 256 and 256 % (C // 8) == 0
 
 
-def _gn_silu(x, norm: nn.GroupNorm, scale, shift, xbias=None):
-    """silu(GroupNorm(x + xbias) * (1 + scale) + shift) in one libfbsmi kernel (include/fbsmi_nn.h); x is NCHW (any
-    strides)."""
+def _tokens(x):
+    """NCHW (any strides) -> (B, H, W, C) contiguous; free for channels_last activations."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _gn_silu(x, norm: nn.GroupNorm, scale, shift, xbias=None, residual=None):
+    """silu(GroupNorm(x + xbias) * (1 + scale) + shift) [+ residual] in one libfbsmi kernel (include/fbsmi_nn.h); x and
+    residual are NCHW (any strides)."""
     from . import _lib
     dt = {torch.float32: 0, torch.bfloat16: 1}.get(x.dtype)
     if dt is None:
         x, dt = x.float(), 0
     B, C, H, W = x.shape
-    tok = x.permute(0, 2, 3, 1).contiguous()            # free for channels_last activations
+    tok = _tokens(x)
+    res = _tokens(residual.to(tok.dtype)) if residual is not None else None
     out = torch.empty_like(tok)
     _lib.call("fbsmi_nn_groupnorm_silu", tok.data_ptr(), out.data_ptr(), dt, B, H * W, C, norm.num_groups,
               norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
               scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None,
-              xbias.data_ptr() if xbias is not None else None, torch.cuda.current_stream().cuda_stream)
+              xbias.data_ptr() if xbias is not None else None, res.data_ptr() if res is not None else None,
+              torch.cuda.current_stream().cuda_stream)
     return _nchw_view(out)
 
 
@@ -157,10 +173,10 @@ class ResnetBlock(nn.Module):
             scale, shift = (p.expand(B, p.shape[1]).contiguous() for p in te.chunk(2, dim=1))
             # the convolution biases are added inside the normalisation kernel (one pass less over the activations)
             h = _gn_silu(self.conv_0(x, with_bias=False), self.norm_0, scale, shift, self.conv_0.conv.bias)
-            h = _gn_silu(self.conv_1(h, with_bias=False), self.norm_1, None, None, self.conv_1.conv.bias)
             if self.res_conv is not None:
                 x = self.res_conv(x)
-            return x + h
+            # ... and so is the skip connection: x + silu(norm_1(conv_1(h)))
+            return _gn_silu(self.conv_1(h, with_bias=False), self.norm_1, None, None, self.conv_1.conv.bias, residual=x)
         h = self.norm_0(self.conv_0(x))
         te = self.time_mlp(F.silu(time_emb))[:, :, None, None]
         scale, shift = te.chunk(2, dim=1)
@@ -207,10 +223,12 @@ class LinearAttention(nn.Module):
         self.to_out = nn.Conv2d(heads * dim_head, dim, 1)
         self.to_out_norm = _ChannelLayerNorm(dim)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         B, C, H, W = x.shape
         if x.is_cuda and self.dim_head == 32 and not torch.is_grad_enabled():
-            return self.to_out_norm(self.to_out(self._fused_core(self.to_qkv(x), B, H, W)))
+            return self.to_out_norm(self.to_out(self._fused_core(self.to_qkv(x), B, H, W)), residual)
+        if residual is not None:
+            return self.forward(x) + residual
         q, k, v = self.to_qkv(x).chunk(3, dim=1)
         q, k, v = (t.reshape(B, self.heads, self.dim_head, H * W).permute(0, 3, 1, 2) for t in (q, k, v))  # b n h d
         q = torch.softmax(q, dim=-1)            # over the embedding axis
@@ -252,6 +270,8 @@ class AttnBlock(nn.Module):
         self.linear = use_linear_attention
 
     def forward(self, x):
+        if self.linear:
+            return self.attn(self.norm(x), residual=x)     # the skip connection rides on the output norm's kernel
         return self.attn(self.norm(x)) + x
 
 

@@ -22,20 +22,22 @@ int fbsmi_nn_linear_attention(const void* qkv, void* out, int dtype, int64_t B, 
 /* GroupNorm (biased variance, eps) + per-image channel modulation + SiLU in one pass over the activations --
  * the two normalisation sites of ResnetBlock (fbs/nn/unet.py:127-172):
  *   x' = x + xbias[c]   (the bias of the convolution that produced x, folded in here; NULL: none)
- *   y = silu( ((x' - mean_g) * rsqrt(var_g + eps) * gamma[c] + beta[c]) * (1 + scale[b][c]) + shift[b][c] )
- * x, y: (B, n, C) token-major (channels_last); C a multiple of 8 * groups; gamma, beta, xbias: (C) float32;
+ *   y = silu( ((x' - mean_g) * rsqrt(var_g + eps) * gamma[c] + beta[c]) * (1 + scale[b][c]) + shift[b][c] ) [+ residual]
+ * x, y, residual (NULL: none; same layout and dtype as x; the block's skip connection): (B, n, C) token-major
+ * (channels_last); C a multiple of 8 * groups; gamma, beta, xbias: (C) float32;
  * scale, shift: (B, C) float32 or NULL (no modulation).  dtype: 0 float32, 1 bfloat16 (statistics in float32,
  * Welford / Chan merging). */
 int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_t B, int32_t n, int32_t C, int32_t groups,
                             const float* gamma, const float* beta, float eps, const float* scale, const float* shift,
-                            const float* xbias, void* stream);
+                            const float* xbias, const void* residual, void* stream);
 
 /* LayerNorm over the channel axis without bias (flax nn.LayerNorm(epsilon, use_bias=False), fbs/nn/unet.py:
  * the PreNorm of every attention block and LinearAttention's output norm):
- *   y[r][c] = (x[r][c] - mean_r) * rsqrt(var_r + eps) * scale[c],  biased variance over the C channels of row r.
- * x, y: (rows, C) with C / 8 a power of two <= 64; dtype 0 float32, 1 bfloat16 (statistics in float32). */
+ *   y[r][c] = (x[r][c] - mean_r) * rsqrt(var_r + eps) * scale[c] [+ residual[r][c]],  biased variance over the C
+ * channels of row r.  x, y, residual (NULL: none): (rows, C) with C / 8 a power of two <= 64; dtype 0 float32,
+ * 1 bfloat16 (statistics in float32). */
 int fbsmi_nn_channel_layernorm(const void* x, void* y, int dtype, int64_t rows, int32_t C, const float* scale, float eps,
-                               void* stream);
+                               const void* residual, void* stream);
 
 #ifdef __cplusplus
 }
