@@ -89,4 +89,3 @@ def test_sharded_world1_equals_unsharded_with_unet(oracle, dev):
                          sb.transition_logpdf, sb.likelihood_logpdf, mask_=mask)
     network_reproducible = all(torch.equal(u, v) for u, v in zip(a, again))
     assert not network_reproducible, "sharded (world 1) and unsharded sweeps differ although the network is reproducible"
-    assert torch.equal(a[2], b[2]) or True   # reference indices may legitimately differ once a weight comparison flips
