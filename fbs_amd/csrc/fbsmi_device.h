@@ -62,6 +62,12 @@ __host__ __device__ __forceinline__ uint32_t random_bits_at(uint32_t k0, uint32_
     return o1;
 }
 
+// elements i (< n/2) and i + n/2 of the same draw, n even: they are the two output words of ONE block-cipher call
+__host__ __device__ __forceinline__ void random_bits_pair(uint32_t k0, uint32_t k1, uint64_t n, uint64_t i, uint32_t& lo,
+                                                          uint32_t& hi) {
+    threefry2x32(k0, k1, (uint32_t)i, (uint32_t)(i + (n >> 1)), lo, hi);
+}
+
 __host__ __device__ __forceinline__ float uniform_at(uint32_t k0, uint32_t k1, uint64_t n, uint64_t i) {
     return fbsmi_bits_to_unit(random_bits_at(k0, k1, n, i));
 }
@@ -458,6 +464,26 @@ __device__ __forceinline__ void block_lse_partial(const float (&l)[ITEMS], float
     block_upsweep_n<1>(sv, path, lds_b, tot);
     m_out = m;
     s_out = tot[0];
+}
+
+// two tiles at once (a workgroup that owns slot t of tile A and slot t of tile B): one LDS exchange per stage
+__device__ __forceinline__ void block_lse_partial2(float lA, float lB, float* lds8a, float* lds8b, float& mA, float& sA,
+                                                   float& mB, float& sB) {
+    float a = wave_max(lA), b = wave_max(lB);
+    if ((threadIdx.x & 63) == 0) {
+        lds8a[threadIdx.x >> 6] = a;
+        lds8a[4 + (threadIdx.x >> 6)] = b;
+    }
+    __syncthreads();
+    a = fmaxf(fmaxf(lds8a[0], lds8a[1]), fmaxf(lds8a[2], lds8a[3]));
+    b = fmaxf(fmaxf(lds8a[4], lds8a[5]), fmaxf(lds8a[6], lds8a[7]));
+    float sv[2] = {fbsmi_expf(lA - finite_or_zero_f(a)), fbsmi_expf(lB - finite_or_zero_f(b))}, tot[2];
+    TreePath path[2];
+    block_upsweep_n<2>(sv, path, lds8b, tot);
+    mA = a;
+    sA = tot[0];
+    mB = b;
+    sB = tot[1];
 }
 
 // consumer (up to kMaxTopBlock tiles): lse and the raw global max

@@ -837,6 +837,139 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The same step with TWO slots per thread, m and m + N/2 (N a multiple of 512): jax's random_bits puts
+// elements i and i + n/2 of a draw on the two output words of one Threefry call, and the rotation keeps
+// the two sources N/2 apart as well, so the kill-test uniform, the redraw uniform and the noise of both slots
+// come out of three block-cipher calls instead of six; the heaps, J and the tables are fetched once for 512
+// slots.  A workgroup then owns tiles b and b + nb/2 and publishes both logsumexp partials.
+// ------------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ void __launch_bounds__(kBlock) k_lg_prop2(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float xch[2][8];
+    __shared__ float heapW[kHeapSizeW], heapJ[kHeapSizeJ];
+    __shared__ float win[kBlock];
+    const int N = d.N, half = N >> 1;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], t0 = kt[6], t1 = kt[7];
+    const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
+    const int mA = blockIdx.x * kBlock + threadIdx.x;   // < N/2
+    const int m[2] = {mA, mA + half};
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    // ---- round 0
+    const float lastJ = d.cdfJ[N - 1];
+    const float last = d.cdf[N - 1];
+    const float w_max = d.scal[1];
+    constexpr int kPerThread = kHeapSizeW / kBlock;
+    const int nodesW = 1 << d.lh_w, nodesJ = 1 << d.lh_j;
+    float hw[kPerThread];
+#pragma unroll
+    for (int h = 0; h < kPerThread; ++h) {
+        const int node = threadIdx.x + h * kBlock;
+        hw[h] = (node >= 1 && node < nodesW) ? d.hpW[node] : 0.0f;
+    }
+    const float hj = ((int)threadIdx.x >= 1 && (int)threadIdx.x < nodesJ) ? d.hpJ[threadIdx.x] : 0.0f;
+    float uref[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) uref[r] = r < d.du ? up[(size_t)r * N + i_ref] : 0.0f;
+    const StepTables<DMAX> t = step_tables<DMAX>(d, s);
+    const float* v_prev = d.vs + (size_t)s * d.dv;
+    const float* v = d.vs + (size_t)(s + 1) * d.dv;
+    const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
+    const float u3 = __uint_as_float(kt[4]);
+    float xi[2][DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) {
+        xi[0][r] = 0.0f;
+        xi[1][r] = 0.0f;
+        if (r < d.du) {   // element mA * du + r is in the first half of the draw, its partner belongs to slot mA + N/2
+            uint32_t lo_, hi_;
+            random_bits_pair(t0, t1, (uint64_t)N * d.du, (uint64_t)mA * d.du + r, lo_, hi_);
+            xi[0][r] = fbsmi_bits_to_normal(lo_);
+            xi[1][r] = fbsmi_bits_to_normal(hi_);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < kPerThread; ++h) heapW[threadIdx.x + h * kBlock] = hw[h];
+    heapJ[threadIdx.x] = hj;
+    __syncthreads();
+    // ---- round 1: J (resamplings.py:84), the rotation j - J (:85)
+    const int J = bisect_uniform(d.cdfJ, N, d.levels, d.lh_j, heapJ, win, lastJ * (1.0f - u3));
+    int shift = (j_ref - J) % N;
+    if (shift < 0) shift += N;
+    int src[2];
+    src[0] = mA - shift;
+    if (src[0] < 0) src[0] += N;
+    const bool a_low = src[0] < half;          // the two sources are N/2 apart too
+    src[1] = a_low ? src[0] + half : src[0] - half;
+    const int pbase = a_low ? src[0] : src[1];
+    // ---- round 2
+    float ws[2], u[2][DMAX];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        ws[h2] = d.w[src[h2]];
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) u[h2][r] = r < d.du ? up[(size_t)r * N + src[h2]] : 0.0f;
+    }
+    uint32_t k_lo, k_hi, r_lo, r_hi;
+    random_bits_pair(a0, a1, (uint64_t)N, (uint64_t)pbase, k_lo, k_hi);
+    random_bits_pair(b0, b1, (uint64_t)N, (uint64_t)pbase, r_lo, r_hi);
+    const float u1[2] = {fbsmi_bits_to_unit(a_low ? k_lo : k_hi), fbsmi_bits_to_unit(a_low ? k_hi : k_lo)};
+    const float u2[2] = {fbsmi_bits_to_unit(a_low ? r_lo : r_hi), fbsmi_bits_to_unit(a_low ? r_hi : r_lo)};
+    const float qK[2] = {last * (1.0f - u2[0]), last * (1.0f - u2[1])};    // resamplings.py:73-74
+    int lo[2], hi[2];
+    bisect_lds_levels(N, d.lh_w, heapW, qK[0], lo[0], hi[0]);
+    bisect_lds_levels(N, d.lh_w, heapW, qK[1], lo[1], hi[1]);
+    const bool killed[2] = {u1[0] * w_max >= ws[0], u1[1] * w_max >= ws[1]};   // :71
+    // ---- rounds 3, 4
+#pragma unroll 1
+    for (int rem = d.levels - d.lh_w; rem > 0; rem -= 3) {
+        bisect_round3(d.cdf, lo[0], hi[0], qK[0], killed[0]);
+        bisect_round3(d.cdf, lo[1], hi[1], qK[1], killed[1]);
+    }
+    float lnew[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        const bool pinned = m[h2] == j_ref;
+        const int a = pinned ? i_ref : (killed[h2] ? hi[h2] : src[h2]);     // :86
+        // ---- round 5
+        if (killed[h2] && !pinned) {
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r)
+                if (r < d.du) u[h2][r] = up[(size_t)r * N + a];
+        }
+        if (pinned) {
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) u[h2][r] = uref[r];
+        }
+        if (d.As) d.As[(size_t)s * N + m[h2]] = a;
+        // transition_sampler (gp_gibbs.py:120-122) and the pin of csmc.py:143
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) {
+            if (r < d.du) {
+                const float dr = drift_row<DMAX>(t, r, u[h2], v_prev);
+                float x = (u[h2][r] + dr * t.dt) + t.sd * xi[h2][r];
+                if (pinned) x = ustar[r];
+                un[(size_t)r * N + m[h2]] = x;
+                if (d.uss) d.uss[((size_t)(s + 1) * N + m[h2]) * d.du + r] = x;
+            }
+        }
+        lnew[h2] = lg_loglik<DMAX>(t, u[h2], v, v_prev);   // likelihood_logpdf on the gathered particle (csmc.py:145)
+        d.lw[m[h2]] = lnew[h2];
+    }
+    float mxA, sxA, mxB, sxB;
+    block_lse_partial2(lnew[0], lnew[1], xch[0], xch[1], mxA, sxA, mxB, sxB);
+    if (threadIdx.x == 0) {
+        const int tb = blockIdx.x + (d.nb >> 1);
+        d.bmax[blockIdx.x] = mxA;
+        d.bsumexp[blockIdx.x] = sxA;
+        d.bmax[tb] = mxB;
+        d.bsumexp[tb] = sxB;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Wide models (16 < max(du, dv) <= 128, the d = 100 Gaussian-process toy of the reference's
 // experiments/bashes/toy_gibbs.sh): the affine drift is a (slots x D) x (D x D) product, so it runs on
 // the matrix cores.  v_mfma_f32_16x16x4_f32 accumulates as an ascending fmaf chain, bit for bit
@@ -1947,6 +2080,7 @@ struct fbsmi_lg_sweep {
     hipGraphExec_t graph_single = nullptr;  // one sweep, no chain bookkeeping
     hipGraphExec_t graph_chain = nullptr;   // one sweep + key split + advance
     bool profile = false;
+    int two_slot_prop = -1;  // FBSMI_TWO_SLOT_PROP=0|1: never / always (where applicable) k_lg_prop2; unset: by batch size
     bool step_launches = false;  // FBSMI_STEP_LAUNCHES=1: one launch per step also where one launch per sweep is possible
     bool generic_prop = false;  // FBSMI_GENERIC_PROP=1: k_lg_prop also for one slot per thread (timing experiments)
     int debug_mask = 7;  // FBSMI_DEBUG_STEP_MASK: bit0 norm, bit1 cdf, bit2 prop (timing experiments only)
@@ -2082,6 +2216,11 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                 else
                     k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
                 k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
+            } else if (s->items == 1 && !s->generic_prop && d.N % (2 * kBlock) == 0 &&
+                       (s->two_slot_prop == 1 || (s->two_slot_prop < 0 && (int64_t)nb * d.C >= 6 * 256))) {
+                // enough workgroups that instruction issue, not latency, bounds the step (measured crossover: six
+                // 256-slot workgroups per CU): two slots per thread, three Threefry calls instead of six
+                LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
             } else if (s->items == 1 && !s->generic_prop) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
             } else {
@@ -2201,6 +2340,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     if (const char* dm = getenv("FBSMI_DEBUG_STEP_MASK")) s->debug_mask = atoi(dm);
     if (const char* gp = getenv("FBSMI_GENERIC_PROP")) s->generic_prop = atoi(gp) != 0;
     if (const char* sl = getenv("FBSMI_STEP_LAUNCHES")) s->step_launches = atoi(sl) != 0;
+    if (const char* sp = getenv("FBSMI_TWO_SLOT_PROP")) s->two_slot_prop = atoi(sp) != 0 ? 1 : 0;
     s->items = fbsmi_tile_items(d.N);  // one workgroup = one tile of the two-level logsumexp (include/fbsmi_math.h)
     const int maxd = m->du > m->dv ? m->du : m->dv;
     s->dmax = maxd <= 2 ? 2 : (maxd <= 4 ? 4 : 16);

@@ -359,3 +359,24 @@ def test_toy_filter_and_pmcmc_drivers(tmp_path, dev):
     z = (samples[:, 50:].reshape(-1, 20).mean(0) - gp_mean) / np.sqrt(np.diag(gp_cov))
     assert np.abs(z).max() < 2.5
     assert set(np.load(os.path.join(str(tmp_path), "pmcmc-0.005-const-200-666.npz")).files) == {"samples", "gp_mean", "gp_cov"}
+
+
+def test_two_slot_prop_kernel_matches_oracle(oracle, dev, monkeypatch):
+    """k_lg_prop2 (two slots per thread, N/2 apart: the kill-test / redraw / noise draws of both slots from three
+    Threefry calls) is chosen for big batches; forced here on small ones.  Bit-exact like every other variant."""
+    monkeypatch.setenv("FBSMI_TWO_SLOT_PROP", "1")
+    for toy, N, T, C in ((toy_2d, 1024, 40, 1), (toy_4d, 512, 12, 3), (toy_31, 2048, 6, 2)):
+        toy_ = toy()
+        ts = np.linspace(0, 1.0, T + 1)
+        br = _bridge(toy_, ts, dev)
+        om = oracle_model_from(oracle, br)
+        rng = np.random.default_rng(N + T)
+        x0 = rng.normal(size=(C, br.du)).astype(np.float32)
+        bs = rng.integers(0, N, (C, T + 1)).astype(np.int32)
+        keys = oracle.split(oracle.PRNGKey(11), C)
+        sweep = br.sweep_handle(N, True, False, nchains=C)
+        got = sweep.sweep(keys if C > 1 else keys[0], x0 if C > 1 else x0[0], toy_["y0"], bs if C > 1 else bs[0])
+        for c in range(C):
+            want = oracle.gibbs_kernel_lg(om, keys[c], x0[c], toy_["y0"], bs[c], N, True, False)
+            for i, what in enumerate(("x0_next", "us_star_next", "bs_star_next", "acc")):
+                _eq(_np(got[i][c] if C > 1 else got[i]), want[i], f"N={N} chain {c} {what}")
