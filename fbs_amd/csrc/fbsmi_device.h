@@ -598,6 +598,65 @@ __device__ __forceinline__ void bisect_lds_levels(int n, int Lh, const float* he
     }
 }
 
+// Two independent searches walking the LDS levels in lockstep (their LDS reads overlap), and taking a
+// three-level round together (all fourteen probes issued before the first is used)
+__device__ __forceinline__ void bisect_lds_levels_x2(int n, int Lh, const float* heap, const float (&q)[2], int (&lo)[2],
+                                                     int (&hi)[2]) {
+    int l0 = 0, h0 = n, t0 = 1, l1 = 0, h1 = n, t1 = 1;
+    for (int l = 0; l < Lh; ++l) {
+        const float v0 = heap[t0], v1 = heap[t1];
+        const int m0 = (l0 + h0) >> 1, m1 = (l1 + h1) >> 1;
+        const bool g0 = q[0] <= v0, g1 = q[1] <= v1;
+        h0 = g0 ? m0 : h0;
+        l0 = g0 ? l0 : m0;
+        t0 = 2 * t0 + (g0 ? 0 : 1);
+        h1 = g1 ? m1 : h1;
+        l1 = g1 ? l1 : m1;
+        t1 = 2 * t1 + (g1 ? 0 : 1);
+    }
+    lo[0] = l0; hi[0] = h0; lo[1] = l1; hi[1] = h1;
+}
+
+__device__ __forceinline__ void bisect_round3_x2(const float* __restrict__ a, int (&lo)[2], int (&hi)[2], const float (&q)[2],
+                                                 const bool (&on)[2]) {
+    int m1[2], m2l[2], m2r[2], m3a[2], m3b[2], m3c[2], m3d[2];
+    float v1[2], v2l[2], v2r[2], v3a[2], v3b[2], v3c[2], v3d[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int l0 = lo[k], h0 = hi[k];
+        m1[k] = (l0 + h0) >> 1;
+        m2l[k] = (l0 + m1[k]) >> 1;
+        m2r[k] = (m1[k] + h0) >> 1;
+        m3a[k] = (l0 + m2l[k]) >> 1;
+        m3b[k] = (m2l[k] + m1[k]) >> 1;
+        m3c[k] = (m1[k] + m2r[k]) >> 1;
+        m3d[k] = (m2r[k] + h0) >> 1;
+        v1[k] = v2l[k] = v2r[k] = v3a[k] = v3b[k] = v3c[k] = v3d[k] = 0.0f;
+        if (on[k]) {
+            v1[k] = a[m1[k]]; v2l[k] = a[m2l[k]]; v2r[k] = a[m2r[k]];
+            v3a[k] = a[m3a[k]]; v3b[k] = a[m3b[k]]; v3c[k] = a[m3c[k]]; v3d[k] = a[m3d[k]];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!on[k]) continue;
+        int l = lo[k], h = hi[k];
+        const bool g1 = q[k] <= v1[k];
+        h = g1 ? m1[k] : h;
+        l = g1 ? l : m1[k];
+        const int m2 = g1 ? m2l[k] : m2r[k];
+        const bool g2 = q[k] <= (g1 ? v2l[k] : v2r[k]);
+        h = g2 ? m2 : h;
+        l = g2 ? l : m2;
+        const int m3 = g1 ? (g2 ? m3a[k] : m3b[k]) : (g2 ? m3c[k] : m3d[k]);
+        const bool g3 = q[k] <= (g1 ? (g2 ? v3a[k] : v3b[k]) : (g2 ? v3c[k] : v3d[k]));
+        h = g3 ? m3 : h;
+        l = g3 ? l : m3;
+        lo[k] = l;
+        hi[k] = h;
+    }
+}
+
 // Three levels in one memory round trip (`on` = false: no loads, interval untouched)
 __device__ __forceinline__ void bisect_round3(const float* __restrict__ a, int& lo, int& hi, float q, bool on) {
     if (!on) return;

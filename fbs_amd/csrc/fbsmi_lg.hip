@@ -919,15 +919,11 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop2(LgDev dd, int s) {
     const float u2[2] = {fbsmi_bits_to_unit(a_low ? r_lo : r_hi), fbsmi_bits_to_unit(a_low ? r_hi : r_lo)};
     const float qK[2] = {last * (1.0f - u2[0]), last * (1.0f - u2[1])};    // resamplings.py:73-74
     int lo[2], hi[2];
-    bisect_lds_levels(N, d.lh_w, heapW, qK[0], lo[0], hi[0]);
-    bisect_lds_levels(N, d.lh_w, heapW, qK[1], lo[1], hi[1]);
+    bisect_lds_levels_x2(N, d.lh_w, heapW, qK, lo, hi);
     const bool killed[2] = {u1[0] * w_max >= ws[0], u1[1] * w_max >= ws[1]};   // :71
     // ---- rounds 3, 4
 #pragma unroll 1
-    for (int rem = d.levels - d.lh_w; rem > 0; rem -= 3) {
-        bisect_round3(d.cdf, lo[0], hi[0], qK[0], killed[0]);
-        bisect_round3(d.cdf, lo[1], hi[1], qK[1], killed[1]);
-    }
+    for (int rem = d.levels - d.lh_w; rem > 0; rem -= 3) bisect_round3_x2(d.cdf, lo, hi, qK, killed);
     float lnew[2];
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
@@ -2217,8 +2213,8 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                     k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
                 k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
             } else if (s->items == 1 && !s->generic_prop && d.N % (2 * kBlock) == 0 &&
-                       (s->two_slot_prop == 1 || (s->two_slot_prop < 0 && (int64_t)nb * d.C >= 6 * 256))) {
-                // enough workgroups that instruction issue, not latency, bounds the step (measured crossover: six
+                       (s->two_slot_prop == 1 || (s->two_slot_prop < 0 && (int64_t)nb * d.C >= 5 * 256))) {
+                // enough workgroups that instruction issue, not latency, bounds the step (measured crossover: between four and six
                 // 256-slot workgroups per CU): two slots per thread, three Threefry calls instead of six
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
             } else if (s->items == 1 && !s->generic_prop) {
