@@ -1,0 +1,157 @@
+"""Gaussian-process regression with the Gibbs sampler on a NON-separable noising process: the closed-form
+Gaussian Schrodinger bridge between the joint (X, Y) prior and a random Gaussian reference.
+
+Counterpart of the reference driver experiments/sb/gibbs.py (same flags, key schedule and .npz schema:
+samples (nsamples, d), gp_mean, gp_cov).  The forward process is an Euler-Maruyama simulation of the bridge's
+affine drift (10 sub-steps per interval) and the closures are written out by the experiment, as in the reference,
+so this runs on the closure tier: the T-loop is a host loop, every sampler-owned operation in it a libfbsmi
+kernel."""
+import argparse
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fbs_amd import ops  # noqa: E402
+from fbs_amd.samplers import bootstrap_filter, gibbs_kernel, stratified  # noqa: E402
+from fbs_amd.samplers.smc import bootstrap_backward_smoother  # noqa: E402
+from fbs_amd.sdes import euler_maruyama, make_gaussian_bw_sb  # noqa: E402
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--d', type=int, default=10, help='The problem dimension.')
+    parser.add_argument('--nparticles', type=int, default=10, help='The number of particles.')
+    parser.add_argument('--nsamples', type=int, default=1000, help='The number of samples to draw.')
+    parser.add_argument('--explicit_backward', action='store_true', default=False)
+    parser.add_argument('--id', type=int, default=666, help='The id of independent MC experiment.')
+    parser.add_argument('--outdir', type=str, default='./sb/results')
+    parser.add_argument('--quiet', action='store_true')
+    args = parser.parse_args(argv)
+    dev = torch.device('cuda:0')
+    key = ops.PRNGKey(args.id)
+
+    # GP setting, sb/gibbs.py:27-60
+    ell, sigma, d, obs_var = 1., 1., args.d, 0.1
+    zs = np.linspace(0., 5., d)
+    cov_mat = sigma ** 2 * np.exp(-np.abs(zs[None, :] - zs[:, None]) / ell)
+    key, subkey = ops.split(key)
+    fs = np.linalg.cholesky(cov_mat) @ ops.normal(subkey, (d,), device=dev).cpu().numpy().astype(np.float64)
+    key, subkey = ops.split(key)
+    y0_np = (fs + np.sqrt(obs_var) * ops.normal(subkey, (d,), device=dev).cpu().numpy()).astype(np.float32)
+    Kyy = cov_mat + obs_var * np.eye(d)
+    gp_mean = cov_mat @ np.linalg.solve(Kyy, y0_np.astype(np.float64))
+    gp_cov = cov_mat - cov_mat @ np.linalg.solve(Kyy, cov_mat)
+    joint_mean = np.zeros(2 * d)
+    joint_cov = np.block([[cov_mat, cov_mat], [cov_mat, Kyy]])
+
+    # reference distribution, sb/gibbs.py:62-67
+    ref_m = np.ones(2 * d)
+    key, subkey = ops.split(key)
+    a_ = ops.normal(subkey, (2 * d, 2 * d), device=dev).cpu().numpy().astype(np.float64)
+    ref_cov = a_ @ a_.T
+
+    # the Schrodinger bridge, sb/gibbs.py:69-75
+    T, nsteps = 1., 100
+    dt = T / nsteps
+    ts = np.linspace(0, T, nsteps + 1)
+    marginal_mean, marginal_cov, drift = make_gaussian_bw_sb(joint_mean, joint_cov, ref_m, ref_cov, sig=1.)
+    y0 = torch.from_numpy(y0_np).to(dev)
+
+    # reverse drift at the grid times as affine maps z -> z R_k^T + r_k  (sb/gibbs.py:82-99: -drift + dispersion^2 score,
+    # both affine for the Gaussian bridge; dispersion = 1)
+    def reverse_affine(t):
+        s_ = T - t
+        mt, covt = marginal_mean(s_), marginal_cov(s_)
+        e = np.eye(2 * d)
+        M = np.stack([drift(e[i], s_) - drift(np.zeros(2 * d), s_) for i in range(2 * d)], axis=1)   # drift = M z + c
+        c = drift(np.zeros(2 * d), s_)
+        P = np.linalg.inv(covt)
+        return -M - P, -c + P @ mt
+
+    tabs = {}
+
+    def rev(t_prev):
+        k = int(round(float(t_prev) / dt))
+        if k not in tabs:
+            R, r = reverse_affine(ts[k])
+            tabs[k] = (torch.as_tensor(R.T.copy(), dtype=torch.float32, device=dev),
+                       torch.as_tensor(r, dtype=torch.float32, device=dev))
+        return tabs[k]
+
+    def reverse_drift_uv(us_prev, v_prev, t_prev):
+        Rt, r = rev(t_prev)
+        uv = torch.cat([us_prev, v_prev.unsqueeze(0).expand(us_prev.shape[0], d)], dim=1)
+        return uv @ Rt + r
+
+    sd = math.sqrt(dt)          # sqrt(dt) * reverse_dispersion, dispersion = 1
+
+    def norm_logpdf_sum(x, loc):
+        return ((math.log(2 * math.pi * sd * sd) + (x - loc) ** 2 / (sd * sd)) / -2.0).sum(dim=1)
+
+    def transition_sampler(us_prev, v_prev, t_prev, key_):                          # sb/gibbs.py:113-115
+        rd = reverse_drift_uv(us_prev, v_prev, t_prev)[:, :d]
+        return us_prev + rd * dt + sd * ops.normal(key_, tuple(us_prev.shape), device=dev)
+
+    def transition_logpdf(u, u_prev, v_prev, t_prev):                               # :118-122
+        rd = reverse_drift_uv(u_prev, v_prev, t_prev)[:, :d]
+        return norm_logpdf_sum(u.unsqueeze(0), u_prev + rd * dt)
+
+    def likelihood_logpdf(v, u_prev, v_prev, t_prev):                               # :125-128
+        rd = reverse_drift_uv(u_prev, v_prev, t_prev)[:, d:]
+        return norm_logpdf_sum(v.unsqueeze(0), v_prev.unsqueeze(0) + rd * dt)
+
+    cy = np.linalg.inv(ref_cov[d:, d:])
+    post_cov = ref_cov[:d, :d] - ref_cov[:d, d:] @ cy @ ref_cov[d:, :d]
+    post_chol = torch.as_tensor(np.linalg.cholesky(post_cov).T.copy(), dtype=torch.float32, device=dev)
+    gain = torch.as_tensor((ref_cov[:d, d:] @ cy).T.copy(), dtype=torch.float32, device=dev)
+    ref_mu, ref_mv = (torch.as_tensor(x, dtype=torch.float32, device=dev) for x in (ref_m[:d], ref_m[d:]))
+
+    def ref_sampler(key_, yT, nsamples_):                                           # :131-134
+        return ref_mu + (yT - ref_mv) @ gain + ops.normal(key_, (nsamples_, d), device=dev) @ post_chol
+
+    def fwd_sampler(key_, x0_, y0_):                                                # :137-139
+        return euler_maruyama(key_, torch.cat([x0_, y0_]), ts, drift, lambda t: 1., integration_nsteps=10,
+                              return_path=True)
+
+    def unpack(xy):
+        return xy[..., :d], xy[..., d:]
+
+    def gibbs_init(key_):                                                           # :150-161
+        key_fwd, key_bwd, key_bf = ops.split(key_, 3)
+        key_x0, key_em = ops.split(key_fwd)
+        xy0 = torch.cat([ops.normal(key_x0, (d,), device=dev), y0])
+        vs = torch.flip(euler_maruyama(key_em, xy0, ts, drift, lambda t: 1., integration_nsteps=10, return_path=True)[:, d:],
+                        [0])
+        uss = bootstrap_filter(transition_sampler, likelihood_logpdf, vs, ts, ref_sampler, key_bf, args.nparticles,
+                               stratified, log=True, return_last=False)[0]
+        return uss[-1, 0], bootstrap_backward_smoother(key_bwd, uss, vs, ts, transition_logpdf), \
+            np.zeros(nsteps + 1, np.int32)
+
+    key, subkey = ops.split(key)                                                    # :171-173
+    x0, us_star, bs_star = gibbs_init(subkey)
+    samples = torch.empty((args.nsamples, d), device=dev)
+    accs = np.zeros(args.nsamples, bool)
+    for i in range(args.nsamples):                                                  # :176-184
+        key, subkey = ops.split(key)
+        x0, us_star, bs_star, acc = gibbs_kernel(subkey, x0, y0, us_star, bs_star, ts, fwd_sampler, None, unpack,
+                                                 args.nparticles, transition_sampler, transition_logpdf, likelihood_logpdf,
+                                                 marg_y=False, explicit_backward=args.explicit_backward, explicit_final=False)
+        samples[i] = x0
+        accs[i] = bool(acc[-1])
+    samples = samples.cpu().numpy()
+    if not args.quiet:
+        burn = min(100, args.nsamples // 2)
+        err = np.abs(samples[burn:].mean(axis=0) - gp_mean).max()
+        print(f'ID: {args.id} | SB Gibbs | {args.nsamples} sweeps | acc rate {accs.mean():.3f} | max |mean - gp_mean| = {err:.3f}')
+    os.makedirs(args.outdir, exist_ok=True)
+    np.savez(os.path.join(args.outdir, f'gibbs{"-eb" if args.explicit_backward else ""}-{args.nparticles}-{args.id}'),
+             samples=samples, gp_mean=gp_mean, gp_cov=gp_cov)                      # :187-188
+    return samples, gp_mean, gp_cov
+
+
+if __name__ == '__main__':
+    main()

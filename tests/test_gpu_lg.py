@@ -380,3 +380,17 @@ def test_two_slot_prop_kernel_matches_oracle(oracle, dev, monkeypatch):
             want = oracle.gibbs_kernel_lg(om, keys[c], x0[c], toy_["y0"], bs[c], N, True, False)
             for i, what in enumerate(("x0_next", "us_star_next", "bs_star_next", "acc")):
                 _eq(_np(got[i][c] if C > 1 else got[i]), want[i], f"N={N} chain {c} {what}")
+
+
+def test_toy_sb_gibbs_driver(tmp_path, dev):
+    """examples/toy_sb_gibbs.py (counterpart of experiments/sb/gibbs.py: Gibbs on the non-separable Gaussian
+    Schrodinger bridge, closure tier with Euler-Maruyama forward paths): runs, stays in the bulk of the GP posterior,
+    writes the reference's .npz schema."""
+    import os
+    mod = _load_example("toy_sb_gibbs")
+    samples, gp_mean, gp_cov = mod.main(["--d", "3", "--nparticles", "16", "--nsamples", "60", "--explicit_backward",
+                                         "--outdir", str(tmp_path), "--quiet"])
+    assert samples.shape == (60, 3) and np.isfinite(samples).all()
+    z = (samples[20:].mean(0) - gp_mean) / np.sqrt(np.diag(gp_cov))
+    assert np.abs(z).max() < 1.5
+    assert set(np.load(os.path.join(str(tmp_path), "gibbs-eb-16-666.npz")).files) == {"samples", "gp_mean", "gp_cov"}
