@@ -43,5 +43,5 @@ def gp_setting(args, dev):
     sde = StationaryLinLinearSDE(beta_min=0.02, beta_max=4., t0=0., T=T) if args.sde == 'lin' \
         else StationaryConstLinearSDE(a=-0.5, b=1.)
     bridge = fbs_amd.LinearGaussianBridge(np.zeros(2 * d), joint_cov, sde, ts, du=d, device=dev)
-    return dict(key=key, d=d, y0=y0, y0_t=torch.from_numpy(y0).to(dev), gp_mean=gp_mean, gp_cov=gp_cov, ts=ts, sde=sde,
+    return dict(key=key, d=d, cov_mat=cov_mat, obs_var=obs_var, y0=y0, y0_t=torch.from_numpy(y0).to(dev), gp_mean=gp_mean, gp_cov=gp_cov, ts=ts, sde=sde,
                 bridge=bridge, nsteps=nsteps)

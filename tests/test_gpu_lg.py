@@ -394,3 +394,16 @@ def test_toy_sb_gibbs_driver(tmp_path, dev):
     z = (samples[20:].mean(0) - gp_mean) / np.sqrt(np.diag(gp_cov))
     assert np.abs(z).max() < 1.5
     assert set(np.load(os.path.join(str(tmp_path), "gibbs-eb-16-666.npz")).files) == {"samples", "gp_mean", "gp_cov"}
+
+
+def test_toy_twisted_driver(tmp_path, dev):
+    """examples/toy_twisted.py (counterpart of experiments/toy/gp_twisted.py): twisted SMC with the twisting gradient
+    through torch autograd; biased but close to the GP posterior, writes the reference's .npz schema."""
+    import os
+    mod = _load_example("toy_twisted")
+    samples, gp_mean, gp_cov = mod.main(["--d", "5", "--nparticles", "64", "--nsamples", "40", "--outdir", str(tmp_path),
+                                         "--quiet"])
+    assert samples.shape == (40, 5) and np.isfinite(samples).all()
+    z = (samples.mean(0) - gp_mean) / np.sqrt(np.diag(gp_cov))
+    assert np.abs(z).max() < 1.5
+    assert set(np.load(os.path.join(str(tmp_path), "twisted-const-64-666.npz")).files) == {"samples", "gp_mean", "gp_cov"}
