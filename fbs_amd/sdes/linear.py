@@ -6,7 +6,6 @@ touches particles or paths runs on the GPU through libfbsmi.
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import numpy as np
 import torch

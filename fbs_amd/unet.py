@@ -243,7 +243,6 @@ class LinearAttention(nn.Module):
 
 def _linear_attention_core(self, qkv, B, H, W):
     """softmaxes, scalings and both einsums of LinearAttention in one libfbsmi kernel (inference, on the GPU)."""
-    import ctypes
     from . import _lib
     dt = {torch.float32: 0, torch.bfloat16: 1}.get(qkv.dtype)
     if dt is None:
