@@ -1279,7 +1279,7 @@ __device__ __forceinline__ void lgw_fpre_body(const LgDev& d, int kres, bool sto
 // instructions in one aligned float4.  S % 64 == 4: the 16 lanes of a ds_read_b128 pass cover all 64 banks.
 // KIND: where the ancestors come from -- 0: d.anc (k_lgw_anc); 1: the Gibbs step prologue, in this
 // workgroup; 2: the filter prologue (resampling key of step kres), in this workgroup; 3: identity (no
-// resampling in front of this product).  tr0 / nrt: the row tiles of this launch; emit bit 0: rows < du
+// resampling in front of this product); 4: d.anc again, with the filters' conventions (k_lgwf_anc).  tr0 / nrt: the row tiles of this launch; emit bit 0: rows < du
 // are written (new particles), bit 1: rows >= du are written (log-density terms).
 template <int KIND>
 __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, int nrt, int Kp, int S, int emit, int kres) {
@@ -1311,11 +1311,11 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     //      ancestor rows (the only dependent loads) go out as soon as the ancestors are here.
     constexpr int kRows = kWideTile / kWaves;   // 8 rows / slots per wave
     int an[kRows];
-    if (KIND == 0 || KIND == 3) {
+    if (KIND == 0 || KIND == 3 || KIND == 4) {
 #pragma unroll
         for (int jj = 0; jj < kRows; ++jj) {
             const int mj = kWideTile * ts + wave + kWaves * jj;
-            an[jj] = mj < N ? (KIND == 0 ? d.anc[mj] : mj) : -1;
+            an[jj] = mj < N ? (KIND == 3 ? mj : d.anc[mj]) : -1;
         }
     }
     const bool vec4 = (D & 3) == 0 && (du & 3) == 0;   // rows are whole float4s: one load per lane and row
@@ -1353,7 +1353,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
             xi[vv] = (r < du && mo < N && (emit & 1)) ? normal_at(t0, t1, (uint64_t)N * du, (uint64_t)mo * du + r) : 0.0f;
         }
     };
-    if (KIND == 0 || KIND == 3) draw_noise();
+    if (KIND == 0 || KIND == 3 || KIND == 4) draw_noise();
     if (KIND == 1 || KIND == 2) {   // the G tile is on its way; now the step's ancestors, worked out by this workgroup itself
         if (KIND == 1) lgw_pre_body<true>(d, s, blockIdx.x == 0, pre, draw_noise);
         else lgw_fpre_body<true>(d, kres, blockIdx.x == 0, pre, draw_noise);
@@ -1598,6 +1598,36 @@ __global__ void __launch_bounds__(kBlock) k_lgwf_init(LgDev dd, const float* u0s
         const float v = u0s[e];
         d.u0[e] = v;
         if (d.uss) d.uss[e] = v;
+    }
+}
+
+// wide particle filters with more than 256 particles: stratified / systematic ancestors of every slot from the
+// global CDF (resampling.py:43-51; the search of k_filt_prop), resampling key of step kres
+__global__ void __launch_bounds__(kBlock) k_lgwf_anc(LgDev dd, int kres) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float heapW[kHeapSize];
+    const int N = d.N, m = blockIdx.x * kBlock + threadIdx.x;
+    if (threadIdx.x >= 1 && threadIdx.x < kHeapSize) heapW[threadIdx.x] = d.cdf[heap_node_mid(threadIdx.x, N)];
+    const uint32_t r0 = d.keytab[8 * kres + 2], r1 = d.keytab[8 * kres + 3];
+    __syncthreads();
+    if (m < N) {
+        const float uu = d.systematic ? uniform_at(r0, r1, 1, 0) : uniform_at(r0, r1, (uint64_t)N, (uint64_t)m);
+        const float q = ((float)m + uu) / (float)N;
+        int a = bisect_heap(d.cdf, N, d.levels, heapW, q);
+        d.anc[m] = a < 0 ? 0 : (a > N - 1 ? N - 1 : a);
+    }
+}
+
+// ... and the final resampled particles us[inds] (smc.py:72 of the last step) from d.anc
+__global__ void __launch_bounds__(kBlock) k_lgwf_gather(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    const float* __restrict__ up = (d.T & 1) ? d.u1 : d.u0;
+    const size_t tot = (size_t)d.N * d.du;
+    for (size_t e = blockIdx.x * (size_t)kBlock + threadIdx.x; e < tot; e += (size_t)gridDim.x * kBlock) {
+        const size_t m = e / d.du, r = e - m * d.du;
+        const float x = up[(size_t)d.anc[m] * d.du + r];
+        d.usT[e] = x;
+        if (d.uss) d.uss[(size_t)d.T * tot + e] = x;
     }
 }
 
@@ -2446,6 +2476,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm_fat, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             fbsmi_lg_sweep_destroy(s);
@@ -2576,13 +2607,43 @@ int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
         return FBSMI_OK;
     }
     if (d.wide) {
-        // one-tile ensembles only (checked at creation): a launch = [filter prologue +] drift product
+        // N <= 256: a launch = [filter prologue +] drift product
         const int nrt = (d.D + kWideTile - 1) / kWideTile, Kp = (d.D + 15) / 16 * 16, S = Kp + ((68 - Kp % 64) % 64);
         const size_t lds = sizeof(float) * 2 * kWideTile * (size_t)S;
         const int nst = (d.N + kWideTile - 1) / kWideTile;
         const int u_tiles = (d.du + kWideTile - 1) / kWideTile;   // row tiles holding rows < du
         const int v_tile0 = d.du / kWideTile;                     // first row tile holding rows >= du
         k_lgwf_init<<<dim3(8, d.C), kBlock, 0, st>>>(d, f->u0s);
+        if (d.N > kBlock) {
+            // several logsumexp tiles: the prologue is its own launches (row sums + partials, normalise, cumsum,
+            // ancestors), the drift product takes the ancestors from d.anc
+            const dim3 gall(nst * nrt, d.C), gu(nst * u_tiles, d.C), gv(nst * (nrt - v_tile0), d.C), gg(64, d.C);
+            auto resample = [&](int kres) {
+                k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
+                k_filt_norm<1><<<gtile, kBlock, 0, st>>>(d);
+                k_lg_cdf<1, 2><<<gtile, kBlock, 0, st>>>(d, d.T);
+                k_lgwf_anc<<<gtile, kBlock, 0, st>>>(d, kres);
+            };
+            if (d.flow == 0) {
+                k_lgw_gemm<3><<<gall, kBlock, lds, st>>>(d, 0, 0, nrt, Kp, S, 3, 0);
+                for (int k = 1; k < d.T; ++k) {
+                    resample(k - 1);
+                    k_lgw_gemm<4><<<gall, kBlock, lds, st>>>(d, k, 0, nrt, Kp, S, 3, 0);
+                }
+                resample(d.T - 1);
+                k_lgwf_gather<<<gg, kBlock, 0, st>>>(d);
+            } else {
+                k_lgw_gemm<3><<<gv, kBlock, lds, st>>>(d, 0, v_tile0, nrt - v_tile0, Kp, S, 2, 0);
+                for (int k = 0; k < d.T; ++k) {
+                    resample(k);
+                    k_lgw_gemm<4><<<gu, kBlock, lds, st>>>(d, k, 0, u_tiles, Kp, S, 1, 0);
+                    if (k + 1 < d.T) k_lgw_gemm<3><<<gv, kBlock, lds, st>>>(d, k + 1, v_tile0, nrt - v_tile0, Kp, S, 2, 0);
+                }
+            }
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("filter launch: ") + hipGetErrorString(e));
+            return FBSMI_OK;
+        }
         if (d.flow == 0) {
             for (int k = 0; k < d.T; ++k) {
                 if (k == 0) k_lgw_gemm<3><<<dim3(nst * nrt, d.C), kBlock, lds, st>>>(d, k, 0, nrt, Kp, S, 3, 0);
@@ -2626,8 +2687,7 @@ int fbsmi_lg_filter_create(const fbsmi_lg_model* m, int32_t nparticles, int flow
     if (!out || flow < 0 || flow > 1 || resampling < 0 || resampling > 1)
         return fail(FBSMI_ERR_ARG, "lg_filter_create: flow must be 0|1 and resampling 0 (stratified) | 1 (systematic)");
     if (flow == 1 && store_path) return fail(FBSMI_ERR_ARG, "lg_filter_create: pmcmc_filter_step keeps no path");
-    if (m && (m->du > 16 || m->dv > 16) && nparticles > kBlock)
-        return fail(FBSMI_ERR_UNSUPPORTED, "lg_filter: du, dv > 16 with more than 256 particles is not supported by the fused filters");
+
     fbsmi_lg_sweep* core = nullptr;
     int rc = fbsmi_lg_sweep_create(m, nparticles, 1, 0, store_path, nchains, &core);
     if (rc) return rc;

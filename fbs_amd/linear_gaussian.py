@@ -194,10 +194,10 @@ class LinearGaussianBridge:
         return max(self.du, self.dv) <= 128 and not explicit_final and nparticles <= 131072
 
     def fused_filter_supported(self, nparticles: int) -> bool:
-        """What fbsmi_lg_filter_create accepts: du, dv <= 16, or du, dv <= 128 with at most 256 particles."""
+        """What fbsmi_lg_filter_create accepts: du, dv <= 16, or du, dv <= 128 with at most 131072 particles."""
         if max(self.du, self.dv) <= 16:
             return True
-        return max(self.du, self.dv) <= 128 and nparticles <= 256
+        return max(self.du, self.dv) <= 128 and nparticles <= 131072
 
     def sweep_handle(self, nparticles: int, explicit_backward=True, explicit_final=False, store_path=None,
                      nchains: int = 1):
