@@ -51,15 +51,13 @@ __host__ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, 
 // element i of jax's random_bits(key, 32, (n,)): counters 0..n-1 padded to even, first half on
 // lane 0 of the block cipher, second half on lane 1.
 __host__ __device__ __forceinline__ uint32_t random_bits_at(uint32_t k0, uint32_t k1, uint64_t n, uint64_t i) {
+    // one block-cipher call whichever half i is in (no divergent double execution when a wave straddles n/2)
     const uint64_t half = (n + 1) >> 1;
+    const bool first = i < half;
+    const uint64_t a = first ? i : i - half, b = a + half;
     uint32_t o0, o1;
-    if (i < half) {
-        const uint64_t j = i + half;
-        threefry2x32(k0, k1, (uint32_t)i, j < n ? (uint32_t)j : 0u, o0, o1);
-        return o0;
-    }
-    threefry2x32(k0, k1, (uint32_t)(i - half), (uint32_t)i, o0, o1);
-    return o1;
+    threefry2x32(k0, k1, (uint32_t)a, b < n ? (uint32_t)b : 0u, o0, o1);
+    return first ? o0 : o1;
 }
 
 // elements i (< n/2) and i + n/2 of the same draw, n even: they are the two output words of ONE block-cipher call

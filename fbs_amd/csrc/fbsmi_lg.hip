@@ -84,6 +84,7 @@ struct LgDev {
     int wide;                               // 16 < max(du, dv) <= 128: row-major particles u0/u1 [N][du], MFMA drift
     float* lpw;                             // [N][dv rounded up to 4] per-row log-density terms of the wide path
     int32_t* anc;                           // [N] ancestors of the current step (wide path)
+    float* xiw;                             // [N][du] the NEXT step's noise, drawn by the previous launch (one-tile wide Gibbs)
     int lh_w, lh_j;                         // their depths
     float* scal;       // [16]: 0 lse, 1 w_max
     int32_t* As;       // [T][N] or null
@@ -148,6 +149,7 @@ __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
     if (d.lpw) {
         d.lpw += (size_t)((d.dv + 3) & ~3) * N * c;
         d.anc += N * c;
+        d.xiw += N * du * c;
     }
     if (d.hpW) {
         d.hpW += (size_t)kHeapSizeW * c;
@@ -994,6 +996,11 @@ __global__ void __launch_bounds__(kBlock) k_lgw_init(LgDev dd) {
             if (d.uss) d.uss[(size_t)p * d.du + r] = v;
         }
     }
+    if (d.N <= kBlock) {   // one-tile ensembles take their noise from d.xiw: step 0's is drawn here (one workgroup: N <= 256)
+        const uint32_t n0 = d.keytab[6], n1 = d.keytab[7];
+        const int total = d.N * d.du;
+        for (int e = threadIdx.x; e < total; e += kBlock) d.xiw[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
+    }
     const int p = p0 + threadIdx.x;
     float lv[1] = {-__builtin_inff()};
     if (p < d.N) {
@@ -1143,11 +1150,15 @@ __device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, 
         else lgw_row_issue(d, t, rows);
     }
     // in the shadow of those loads: the caller's work and the three uniforms of this thread -- as a SOURCE
-    // slot p = t it owns the kill test and the redraw of p (resamplings.py:71-74), whatever the rotation
+    // slot p = t it owns the kill test and the redraw of p (resamplings.py:71-74), whatever the rotation.
+    // (The scheduling barrier keeps the compiler from sinking the loads below this ALU work.)
+    __builtin_amdgcn_sched_barrier(0);
     early();
     const float u3 = __uint_as_float(kt[4]);
     const float u1 = live ? uniform_at(a0, a1, (uint64_t)N, (uint64_t)t) : 0.0f;
     const float u2 = live ? uniform_at(b0, b1, (uint64_t)N, (uint64_t)t) : 0.0f;
+    FBSMI_STAMP(31)
+    __builtin_amdgcn_sched_barrier(0);
     if (ROWS && live && s) {
         l = lgw_row_add(d, rows);
         if (store) d.lw[t] = l;
@@ -1346,16 +1357,38 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     float xi[4];
 #pragma unroll
     for (int vv = 0; vv < 4; ++vv) acc[vv] = row0 + vv < D ? g[row0 + vv] : 0.0f;
+    // Four independent Threefry + erf_inv chains in one basic block (the compiler interleaves them: a lone
+    // dependent chain issues one instruction every ~7 clocks); skipped as a whole by row tiles without rows < du.
     auto draw_noise = [&]() {
 #pragma unroll
-        for (int vv = 0; vv < 4; ++vv) {
-            const int r = row0 + vv;
-            xi[vv] = (r < du && mo < N && (emit & 1)) ? normal_at(t0, t1, (uint64_t)N * du, (uint64_t)mo * du + r) : 0.0f;
+        for (int vv = 0; vv < 4; ++vv) xi[vv] = 0.0f;
+        if ((emit & 1) && kWideTile * tr < du) {
+            uint32_t bits[4];
+#pragma unroll
+            for (int vv = 0; vv < 4; ++vv) {
+                const int r = row0 + vv;
+                const bool ok = r < du && mo < N;
+                bits[vv] = random_bits_at(t0, t1, (uint64_t)N * du, ok ? (uint64_t)mo * du + r : 0ull);
+            }
+#pragma unroll
+            for (int vv = 0; vv < 4; ++vv) {
+                const float z = fbsmi_bits_to_normal(bits[vv]);
+                xi[vv] = (row0 + vv < du && mo < N) ? z : 0.0f;
+            }
         }
     };
     if (KIND == 0 || KIND == 3 || KIND == 4) draw_noise();
+    // One-tile Gibbs: this step's noise was drawn by the PREVIOUS launch (every workgroup a share, at its end, where
+    // the workgroups without rows < du would otherwise idle): ~1600 VALU instructions off the critical path.
+    auto fetch_noise = [&]() {
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) {
+            const int r = row0 + vv;
+            xi[vv] = (r < du && mo < N) ? d.xiw[(size_t)mo * du + r] : 0.0f;
+        }
+    };
     if (KIND == 1 || KIND == 2) {   // the G tile is on its way; now the step's ancestors, worked out by this workgroup itself
-        if (KIND == 1) lgw_pre_body<true>(d, s, blockIdx.x == 0, pre, draw_noise);
+        if (KIND == 1) lgw_pre_body<true>(d, s, blockIdx.x == 0, pre, fetch_noise);
         else lgw_fpre_body<true>(d, kres, blockIdx.x == 0, pre, draw_noise);
 #pragma unroll
         for (int jj = 0; jj < kRows; ++jj) {
@@ -1440,6 +1473,19 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
                 d.lpw[(size_t)mo * ((d.dv + 3) & ~3) + rv] = norm_logpdf(v[rv], cond_m, sd2, lognorm);
             }
         }
+    }
+    FBSMI_STAMP(30)
+#ifdef FBSMI_STAMPS
+    const bool stamp_tail = true;   // diagnostic build: time the tail on the last step too (its draws are never used)
+#else
+    const bool stamp_tail = false;
+#endif
+    if (KIND == 1 && (s + 1 < d.T || stamp_tail)) {   // this workgroup's share of the next step's noise
+        const int sn = s + 1 < d.T ? s + 1 : s;
+        const uint32_t n0 = d.keytab[8 * sn + 6], n1 = d.keytab[8 * sn + 7];
+        const int total = N * du, per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int e0 = (int)blockIdx.x * per, e1 = e0 + per < total ? e0 + per : total;
+        for (int e = e0 + t; e < e1; e += kBlock) d.xiw[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
     }
     FBSMI_STAMP(24)
 }
@@ -2407,9 +2453,11 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     rc |= slab_request(s, &d.bmax, C * d.nb);
     rc |= slab_request(s, &d.bsumexp, C * d.nb);
     d.anc = nullptr;
+    d.xiw = nullptr;
     if (wide) {
         rc |= slab_request(s, &d.lpw, C * (size_t)((d.dv + 3) & ~3) * N);
         rc |= slab_request(s, &d.anc, C * N);
+        rc |= slab_request(s, &d.xiw, C * N * d.du);
     }
     d.hpW = d.hpJ = nullptr;
     d.hp_map = nullptr;

@@ -39,7 +39,10 @@ int main(int argc, char** argv) {
         printf("(d=100, N=%d, chains=%d; the last step of a sweep)\n", N, C);
         return 0;
     }
-    int order[] = {20, 25, 26, 27, 28, 29, 21, 22, 23, 24};
+    names[31] = "pre own draws done (row loads in flight)";
+    names[30] = "gemm outputs stored";
+    names[24] = "gemm out (next step's noise share drawn)";
+    int order[] = {20, 25, 31, 26, 27, 28, 29, 21, 22, 23, 30, 24};
     double t0 = rt(20), prev = t0;
     for (int i : order) { printf("%-32s t=%8.0f ns  (+%6.0f)\n", names[i], rt(i) - t0, rt(i) - prev); prev = rt(i); }
     printf("(d=100, N=%d, chains=%d; the last step of a sweep)\n", N, C);
