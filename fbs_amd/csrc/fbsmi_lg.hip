@@ -987,11 +987,15 @@ __global__ void __launch_bounds__(kBlock) k_lgw_init(LgDev dd) {
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float xch[2][4];
     const int p0 = blockIdx.x * kBlock;
-    // gibbs.py:140-144 (explicit_final=False): every particle starts at us_star[0], weights 1/N
+    // gibbs.py:140-144 (explicit_final=False): every particle starts at us_star[0], weights 1/N;
+    // gibbs.py:132-138 (explicit_final=True): N(0, I) draws except the pinned slot, weights from the
+    // likelihood -- those come from a drift product on these particles (the launch after this one)
+    const int b0 = d.bs[0];
     for (int e = threadIdx.x; e < kBlock * d.du; e += kBlock) {
         const int p = p0 + e / d.du, r = e % d.du;
         if (p < d.N) {
-            const float v = d.us_star[r];
+            float v = d.us_star[r];
+            if (d.ef && p != b0) v = normal_at(d.misc[2], d.misc[3], (uint64_t)d.N * d.du, (uint64_t)p * d.du + r);
             d.u0[(size_t)p * d.du + r] = v;
             if (d.uss) d.uss[(size_t)p * d.du + r] = v;
         }
@@ -1146,7 +1150,7 @@ __device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, 
     LgwRowLoads rows;
     float l = 0.0f;
     if (live) {
-        if (!ROWS || s == 0) l = d.lw[t];
+        if (!ROWS || (s == 0 && !d.ef)) l = d.lw[t];
         else lgw_row_issue(d, t, rows);
     }
     // in the shadow of those loads: the caller's work and the three uniforms of this thread -- as a SOURCE
@@ -1159,7 +1163,7 @@ __device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, 
     const float u2 = live ? uniform_at(b0, b1, (uint64_t)N, (uint64_t)t) : 0.0f;
     FBSMI_STAMP(31)
     __builtin_amdgcn_sched_barrier(0);
-    if (ROWS && live && s) {
+    if (ROWS && live && (s || d.ef)) {
         l = lgw_row_add(d, rows);
         if (store) d.lw[t] = l;
     }
@@ -1313,8 +1317,11 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     const float* __restrict__ g = d.g + (size_t)s * D;
     const float sd = d.sd[s], lognorm = d.lognorm[s];
     const float sd2 = sd * sd;
-    const float* v_prev = d.vs + (size_t)s * d.dv;
-    const float* v = d.vs + (size_t)(s + 1) * d.dv;
+    // (KIND 3 with kres = 1: the initial weights of explicit_final, likelihood_logpdf(vs[0], u0s, vs[1], ts[0]) --
+    // the observation pair the other way round, gibbs.py:136-137)
+    const bool swap_v = KIND == 3 && kres == 1;
+    const float* v_prev = d.vs + (size_t)(swap_v ? s + 1 : s) * d.dv;
+    const float* v = d.vs + (size_t)(swap_v ? s : s + 1) * d.dv;
     const float* ustar = d.us_star + (size_t)(s + 1) * du;
     FBSMI_STAMP(20)
     // ---- round 0.  Wave w stages rows / slots w, w+4, ... of the two tiles.  The ancestors are asked for
@@ -2256,8 +2263,15 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     const int w_S = w_Kp + ((68 - w_Kp % 64) % 64);   // >= Kp, == 4 (mod 64)
     const size_t w_lds = sizeof(float) * 2 * kWideTile * (size_t)w_S;
     const dim3 gwide(((d.N + kWideTile - 1) / kWideTile) * w_nrt, d.C);
-    if (d.wide) k_lgw_init<<<gtile, kBlock, 0, st>>>(d);
-    else LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d)));
+    if (d.wide) {
+        k_lgw_init<<<gtile, kBlock, 0, st>>>(d);
+        if (d.ef) {   // initial log-weights: rows >= du of the drift product on the initial particles, no resampling
+            const int v_tile0 = d.du / kWideTile;
+            k_lgw_gemm<3><<<dim3(((d.N + kWideTile - 1) / kWideTile) * (w_nrt - v_tile0), d.C), kBlock, w_lds, st>>>(
+                d, 0, v_tile0, w_nrt - v_tile0, w_Kp, w_S, 2, 1);
+            if (d.N > kBlock) k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);   // several tiles: lw + partials for k_lg_norm
+        }
+    } else LG_DISPATCH(s, (k_lg_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d)));
     const bool one_tile = d.N <= kBlock && !s->generic_prop;   // the steps need no grid-wide stage of their own
     const bool persistent = one_tile && !d.wide && !s->profile && !s->step_launches;
     if (persistent) LG_DISPATCH(s, (void)ITEMS; (k_lg_sweep1<DMAX><<<gone, kBlock, 0, st>>>(d)));
@@ -2384,8 +2398,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     const bool wide = m->du > 16 || m->dv > 16;
     if (wide && (m->du > 128 || m->dv > 128))
         return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: du, dv > 128 are not supported by the fused sweep");
-    if (wide && explicit_final)
-        return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: explicit_final with du, dv > 16 is not supported by the fused sweep");
+
     if (wide && (explicit_final ? nparticles + 1 : nparticles) > 131072)
         return fail(FBSMI_ERR_UNSUPPORTED, "lg_sweep: du, dv > 16 with more than 131072 particles is not supported");
     if (!explicit_backward && !store_path)

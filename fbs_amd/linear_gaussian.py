@@ -187,11 +187,11 @@ class LinearGaussianBridge:
     # -- fused engine ----------------------------------------------------------------------------
     def fused_sweep_supported(self, nparticles: int, explicit_final: bool = False) -> bool:
         """What fbsmi_lg_sweep_create accepts: du, dv <= 16 at any ensemble size up to 4M particles; du, dv <= 128
-        (drift on the matrix cores) with explicit_final=False and at most 131072 particles."""
+        (drift on the matrix cores) with at most 131072 slots (particles + 1 with explicit_final)."""
         wide = max(self.du, self.dv) > 16
         if not wide:
             return True
-        return max(self.du, self.dv) <= 128 and not explicit_final and nparticles <= 131072
+        return max(self.du, self.dv) <= 128 and nparticles + (1 if explicit_final else 0) <= 131072
 
     def fused_filter_supported(self, nparticles: int) -> bool:
         """What fbsmi_lg_filter_create accepts: du, dv <= 16, or du, dv <= 128 with at most 131072 particles."""

@@ -68,7 +68,7 @@ def test_capacity_limits(oracle, dev):
     with pytest.raises(RuntimeError):
         br.sweep_handle(0)
     # du, dv > 128 exceed the matrix-core drift kernel: the fused engine refuses, the dispatcher falls back to the
-    # closure tier; so does explicit_final=True on a wide model
+    # closure tier
     rng = np.random.default_rng(0)
     A = rng.normal(size=(260, 260))
     big = fbs_amd.LinearGaussianBridge(np.zeros(260), A @ A.T / 260 + np.eye(260), StationaryConstLinearSDE(-0.5, 1.0),
@@ -80,18 +80,12 @@ def test_capacity_limits(oracle, dev):
                        np.zeros(4, np.int32), np.linspace(0, 1, 4), big.fwd_sampler, big.sde, big.unpack, 32,
                        big.transition_sampler, big.transition_logpdf, big.likelihood_logpdf)
     assert out[1].shape == (4, 130) and torch.isfinite(out[1]).all()
-    A = rng.normal(size=(40, 40))
-    mid = fbs_amd.LinearGaussianBridge(np.zeros(40), A @ A.T / 40 + np.eye(40), StationaryConstLinearSDE(-0.5, 1.0),
-                                       np.linspace(0, 1, 6), 20, device=dev)
-    with pytest.raises(NotImplementedError):
-        mid.sweep_handle(64, explicit_final=True)
-    assert not mid.fused_sweep_supported(64, explicit_final=True) and mid.fused_sweep_supported(64)
 
 
 def test_large_dimension_closures_match_oracle(oracle, dev):
-    """du = dv = 20 (the d-dimensional GP toy of gp_gibbs.py:32-58 has joint dimension 2d): the closure tier
-    (forced here through a kwarg-free call with explicit_final, which the fused engine does not take for wide
-    models) and the fused engine, both bit-exact against the oracle."""
+    """du = dv = 20 (the d-dimensional GP toy of gp_gibbs.py:32-58 has joint dimension 2d): the fused engine
+    (through gibbs_kernel's dispatch) and the closure tier (plain lambdas hide the bridge), both bit-exact
+    against the oracle."""
     import fbs_amd
     from fbs_amd.samplers import gibbs_kernel
     from fbs_amd.sdes import StationaryConstLinearSDE
@@ -108,12 +102,13 @@ def test_large_dimension_closures_match_oracle(oracle, dev):
     x0 = rng.normal(size=d).astype(np.float32)
     bs = rng.integers(0, 48, 9).astype(np.int32)
     key = oracle.PRNGKey(17)
-    for ef in (False, True):        # ef=False: fused (matrix-core drift); ef=True: closure tier
-        assert br.fused_sweep_supported(48, ef) == (not ef)
-        got = gibbs_kernel(key, torch.from_numpy(x0).to(dev), torch.from_numpy(y0).to(dev), None, bs, ts, br.fwd_sampler,
-                           br.sde, br.unpack, 48, br.transition_sampler, br.transition_logpdf, br.likelihood_logpdf,
-                           explicit_final=ef)
+    for ef in (False, True):
+        assert br.fused_sweep_supported(48, ef)
         want = oracle.gibbs_kernel_lg(om, key, x0, y0, bs, 48, True, ef)
-        for a, b in zip(got, want):
-            a = a.cpu().numpy()
-            assert np.array_equal(a.view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), f"explicit_final={ef}"
+        for tier in ("fused", "closure"):
+            ls = br.likelihood_logpdf if tier == "fused" else (lambda *a, **k: br.likelihood_logpdf(*a, **k))
+            got = gibbs_kernel(key, torch.from_numpy(x0).to(dev), torch.from_numpy(y0).to(dev), None, bs, ts, br.fwd_sampler,
+                               br.sde, br.unpack, 48, br.transition_sampler, br.transition_logpdf, ls, explicit_final=ef)
+            for a, b in zip(got, want):
+                a = a.cpu().numpy()
+                assert np.array_equal(a.view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), f"{tier}, explicit_final={ef}"

@@ -407,3 +407,28 @@ def test_toy_twisted_driver(tmp_path, dev):
     z = (samples.mean(0) - gp_mean) / np.sqrt(np.diag(gp_cov))
     assert np.abs(z).max() < 1.5
     assert set(np.load(os.path.join(str(tmp_path), "twisted-const-64-666.npz")).files) == {"samples", "gp_mean", "gp_cov"}
+
+
+@pytest.mark.parametrize("du,dv,N,T,eb", [(24, 24, 40, 6, True), (33, 17, 255, 4, False), (20, 20, 300, 5, True)])
+def test_wide_fused_sweep_explicit_final(du, dv, N, T, eb, oracle, dev):
+    """explicit_final=True on the matrix-core path: N + 1 slots, N(0, I) initial particles, initial weights from a
+    drift product with the observation pair swapped (gibbs.py:132-138)."""
+    toy = toy_gp(du, dv)
+    ts = np.linspace(0, 1.0, T + 1)
+    br = _bridge(toy, ts, dev)
+    om = oracle_model_from(oracle, br)
+    rng = np.random.default_rng(du + N)
+    x0 = rng.normal(size=du).astype(np.float32)
+    bs = rng.integers(0, N + 1, T + 1).astype(np.int32)
+    assert br.fused_sweep_supported(N, True)
+    sweep = br.sweep_handle(N, eb, True)
+    for trial in range(2):
+        key = oracle.split(oracle.PRNGKey(21 + trial), 2)[1]
+        want = oracle.gibbs_kernel_lg(om, key, x0, toy["y0"], bs, N, eb, True, debug=True)
+        got = sweep.sweep(key, x0, toy["y0"], bs)
+        v = sweep.views()
+        _eq(_np(v["us_T"]), want[4], "final particles")
+        _eq(_np(v["lw_T"]), want[5], "final log-weights")
+        for i, what in enumerate(("x0_next", "us_star_next", "bs_star_next", "acc")):
+            _eq(_np(got[i]), want[i], what)
+        x0, bs = want[0], want[2]
