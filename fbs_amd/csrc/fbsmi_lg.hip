@@ -2206,17 +2206,20 @@ int slab_commit(fbsmi_lg_sweep* s) {
     do {                                                                                      \
         if ((s)->items == 1) {                                                                \
             constexpr int ITEMS = 1;                                                          \
-            if ((s)->dmax == 2) { constexpr int DMAX = 2; __VA_ARGS__; }                      \
+            if ((s)->dmax == 1) { constexpr int DMAX = 1; __VA_ARGS__; }                      \
+            else if ((s)->dmax == 2) { constexpr int DMAX = 2; __VA_ARGS__; }                 \
             else if ((s)->dmax == 4) { constexpr int DMAX = 4; __VA_ARGS__; }                 \
             else { constexpr int DMAX = 16; __VA_ARGS__; }                                    \
         } else if ((s)->items == 4) {                                                         \
             constexpr int ITEMS = 4;                                                          \
-            if ((s)->dmax == 2) { constexpr int DMAX = 2; __VA_ARGS__; }                      \
+            if ((s)->dmax == 1) { constexpr int DMAX = 1; __VA_ARGS__; }                      \
+            else if ((s)->dmax == 2) { constexpr int DMAX = 2; __VA_ARGS__; }                 \
             else if ((s)->dmax == 4) { constexpr int DMAX = 4; __VA_ARGS__; }                 \
             else { constexpr int DMAX = 16; __VA_ARGS__; }                                    \
         } else {                                                                              \
             constexpr int ITEMS = 16;                                                         \
-            if ((s)->dmax == 2) { constexpr int DMAX = 2; __VA_ARGS__; }                      \
+            if ((s)->dmax == 1) { constexpr int DMAX = 1; __VA_ARGS__; }                      \
+            else if ((s)->dmax == 2) { constexpr int DMAX = 2; __VA_ARGS__; }                 \
             else if ((s)->dmax == 4) { constexpr int DMAX = 4; __VA_ARGS__; }                 \
             else { constexpr int DMAX = 16; __VA_ARGS__; }                                    \
         }                                                                                     \
@@ -2428,7 +2431,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     if (const char* sp = getenv("FBSMI_TWO_SLOT_PROP")) s->two_slot_prop = atoi(sp) != 0 ? 1 : 0;
     s->items = fbsmi_tile_items(d.N);  // one workgroup = one tile of the two-level logsumexp (include/fbsmi_math.h)
     const int maxd = m->du > m->dv ? m->du : m->dv;
-    s->dmax = maxd <= 2 ? 2 : (maxd <= 4 ? 4 : 16);
+    s->dmax = maxd <= 1 ? 1 : (maxd <= 2 ? 2 : (maxd <= 4 ? 4 : 16));   // du = dv = 1 (BASELINE configs 1, 2) has its own instantiation
     const int tile = kBlock * s->items;
     d.nb = (d.N + tile - 1) / tile;
     if (d.nb > kMaxNbSweep) {
