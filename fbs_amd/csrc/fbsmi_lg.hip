@@ -732,7 +732,8 @@ template <int DMAX>
 __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float xch[2][4];
-    __shared__ float heapW[kHeapSizeW], heapJ[kHeapSizeJ];
+    __shared__ __attribute__((aligned(16))) float heapW[kHeapSizeW];
+    __shared__ float heapJ[kHeapSizeJ];
     __shared__ float win[kBlock];
     FBSMI_STAMP(6)
     const int N = d.N;
@@ -747,15 +748,11 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
     const float lastJ = d.cdfJ[N - 1];
     const float last = d.cdf[N - 1];
     const float w_max = d.scal[1];
-    constexpr int kPerThread = kHeapSizeW / kBlock;
-    const int nodesW = 1 << d.lh_w, nodesJ = 1 << d.lh_j;
-    float hw[kPerThread];
-#pragma unroll
-    for (int h = 0; h < kPerThread; ++h) {
-        const int node = threadIdx.x + h * kBlock;
-        hw[h] = (node >= 1 && node < nodesW) ? d.hpW[node] : 0.0f;
-    }
-    const float hj = ((int)threadIdx.x >= 1 && (int)threadIdx.x < nodesJ) ? d.hpJ[threadIdx.x] : 0.0f;
+    // the compact heaps, whole (nodes past the published depth are zero and never visited): two float4 per thread
+    static_assert(kHeapSizeW == 8 * kBlock && kHeapSizeJ == kBlock, "heap staging assumes 2048 / 256 nodes");
+    const float4 hw0 = reinterpret_cast<const float4*>(d.hpW)[2 * threadIdx.x];
+    const float4 hw1 = reinterpret_cast<const float4*>(d.hpW)[2 * threadIdx.x + 1];
+    const float hj = d.hpJ[threadIdx.x];
     float uref[DMAX];
 #pragma unroll
     for (int r = 0; r < DMAX; ++r) uref[r] = r < d.du ? up[(size_t)r * N + i_ref] : 0.0f;
@@ -768,8 +765,8 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
 #pragma unroll
     for (int r = 0; r < DMAX; ++r)
         xi[r] = (r < d.du && live) ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r) : 0.0f;
-#pragma unroll
-    for (int h = 0; h < kPerThread; ++h) heapW[threadIdx.x + h * kBlock] = hw[h];
+    reinterpret_cast<float4*>(heapW)[2 * threadIdx.x] = hw0;
+    reinterpret_cast<float4*>(heapW)[2 * threadIdx.x + 1] = hw1;
     heapJ[threadIdx.x] = hj;
     FBSMI_STAMP(7)
     __syncthreads();
@@ -849,7 +846,8 @@ template <int DMAX>
 __global__ void __launch_bounds__(kBlock) k_lg_prop2(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float xch[2][8];
-    __shared__ float heapW[kHeapSizeW], heapJ[kHeapSizeJ];
+    __shared__ __attribute__((aligned(16))) float heapW[kHeapSizeW];
+    __shared__ float heapJ[kHeapSizeJ];
     __shared__ float win[kBlock];
     const int N = d.N, half = N >> 1;
     const uint32_t* kt = d.keytab + 8 * s;
@@ -863,15 +861,11 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop2(LgDev dd, int s) {
     const float lastJ = d.cdfJ[N - 1];
     const float last = d.cdf[N - 1];
     const float w_max = d.scal[1];
-    constexpr int kPerThread = kHeapSizeW / kBlock;
-    const int nodesW = 1 << d.lh_w, nodesJ = 1 << d.lh_j;
-    float hw[kPerThread];
-#pragma unroll
-    for (int h = 0; h < kPerThread; ++h) {
-        const int node = threadIdx.x + h * kBlock;
-        hw[h] = (node >= 1 && node < nodesW) ? d.hpW[node] : 0.0f;
-    }
-    const float hj = ((int)threadIdx.x >= 1 && (int)threadIdx.x < nodesJ) ? d.hpJ[threadIdx.x] : 0.0f;
+    // the compact heaps, whole (nodes past the published depth are zero and never visited): two float4 per thread
+    static_assert(kHeapSizeW == 8 * kBlock && kHeapSizeJ == kBlock, "heap staging assumes 2048 / 256 nodes");
+    const float4 hw0 = reinterpret_cast<const float4*>(d.hpW)[2 * threadIdx.x];
+    const float4 hw1 = reinterpret_cast<const float4*>(d.hpW)[2 * threadIdx.x + 1];
+    const float hj = d.hpJ[threadIdx.x];
     float uref[DMAX];
 #pragma unroll
     for (int r = 0; r < DMAX; ++r) uref[r] = r < d.du ? up[(size_t)r * N + i_ref] : 0.0f;
@@ -892,8 +886,8 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop2(LgDev dd, int s) {
             xi[1][r] = fbsmi_bits_to_normal(hi_);
         }
     }
-#pragma unroll
-    for (int h = 0; h < kPerThread; ++h) heapW[threadIdx.x + h * kBlock] = hw[h];
+    reinterpret_cast<float4*>(heapW)[2 * threadIdx.x] = hw0;
+    reinterpret_cast<float4*>(heapW)[2 * threadIdx.x + 1] = hw1;
     heapJ[threadIdx.x] = hj;
     __syncthreads();
     // ---- round 1: J (resamplings.py:84), the rotation j - J (:85)
