@@ -63,10 +63,10 @@ FBSMI_HD float fbsmi_sqrtf(float x) { return __builtin_sqrtf(x); }
  * float32 (checked exhaustively by tests/test_math_spec.py): max_i exp(x_i) == exp(max_i x_i)
  * is an identity for it, which the HIP path uses for the killing resampler's w_max. */
 FBSMI_HD float fbsmi_expf(float x) {
-    if (x != x) return x + x;
-    if (x < -87.3f) return 0.0f;
-    if (x > 88.72283f) return fbsmi_u2f(FBSMI_INF_BITS);
-    const double xd = (double)x;
+    /* Straight-line: the special cases are selected at the end (same values as early returns), so that
+     * several exps in one basic block can be interleaved by the compiler.  The clamp only keeps the
+     * discarded lanes' exponent arithmetic in range. */
+    const double xd = __builtin_fmin(__builtin_fmax((double)x, -100.0), 100.0);
     const double k = __builtin_rint(xd * 1.4426950408889634);
     double r = __builtin_fma(k, -6.93147180369123816490e-01, xd);
     r = __builtin_fma(k, -1.90821492927058770002e-10, r);
@@ -86,7 +86,10 @@ FBSMI_HD float fbsmi_expf(float x) {
     uint64_t sb = (uint64_t)(ki + 1023) << 52;
     double sc;
     __builtin_memcpy(&sc, &sb, 8);
-    return (float)(p * sc);
+    float y = (float)(p * sc);
+    y = x < -87.3f ? 0.0f : y;
+    y = x > 88.72283f ? fbsmi_u2f(FBSMI_INF_BITS) : y;
+    return x != x ? x + x : y;
 }
 
 /* log(x), the classic msun/fdlibm single-precision scheme: x = 2^e m, m in [sqrt(1/2), sqrt(2)),
