@@ -2343,7 +2343,10 @@ int get_graph(fbsmi_lg_sweep* s, int chain, hipGraphExec_t* out) {
         FBSMI_HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
         int rc = enqueue_sweep(s, s->stream, chain);
         hipError_t e = hipStreamEndCapture(s->stream, &g);
-        if (rc) return rc;
+        if (rc) {
+            if (g) hipGraphDestroy(g);
+            return rc;
+        }
         if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         FBSMI_HIP_TRY(hipGraphInstantiate(&slot, g, nullptr, nullptr, 0));
         FBSMI_HIP_TRY(hipGraphDestroy(g));
@@ -2528,8 +2531,10 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         return fail(FBSMI_ERR_HIP, "lg_sweep_create: stream/event creation failed");
     }
     if (wide) {
-        const int Kp = (d.D + 15) / 16 * 16, S = Kp + ((68 - Kp % 64) % 64);
-        const int lds = (int)(sizeof(float) * 2 * kWideTile * S);
+        // The attribute belongs to the function, not to the handle: always ask for the largest tile pair any model can
+        // need (D = 256), or a later handle with a smaller model would lower the limit under an earlier one.
+        constexpr int kKpMax = 256, kSMax = kKpMax + ((68 - kKpMax % 64) % 64);
+        const int lds = (int)(sizeof(float) * 2 * kWideTile * kSMax);
         hipError_t e = hipFuncSetAttribute((const void*)k_lgw_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

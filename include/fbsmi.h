@@ -145,7 +145,9 @@ typedef struct fbsmi_lg_sweep fbsmi_lg_sweep; /* opaque: device buffers + captur
  * `nparticles` particles, for `nchains` independent chains batched in every launch -- the
  * reference's jax.vmap over chains (experiments/toy/gp_gibbs.py:25,172-173).  store_path != 0 keeps
  * As / uss / log_wss (needed when explicit_backward == 0).  Allocates device memory (not
- * stream-ordered; call once).  All per-chain arrays below are laid out [nchains][...]. */
+ * stream-ordered; call once).  All per-chain arrays below are laid out [nchains][...].
+ * A handle owns one launch stream and one set of buffers: calls on the SAME handle must not overlap
+ * (drive a handle from one host thread at a time); different handles are independent. */
 int fbsmi_lg_sweep_create(const fbsmi_lg_model* model, int32_t nparticles, int explicit_backward,
                           int explicit_final, int store_path, int32_t nchains, fbsmi_lg_sweep** out);
 void fbsmi_lg_sweep_destroy(fbsmi_lg_sweep* s);

@@ -149,6 +149,26 @@ def test_wide_fused_sweep_matches_oracle(du, dv, N, T, eb, oracle, dev):
         x0, bs = want[0], want[2]
 
 
+def test_wide_handles_of_different_widths_coexist(oracle, dev):
+    """The dynamic-LDS limit of the drift kernels is a per-function attribute: creating a handle for a small model
+    must not lower it under a live handle of a large one."""
+    T, N = 3, 33
+    ts = np.linspace(0, 1.0, T + 1)
+    big, small = toy_gp(128), toy_gp(20)
+    br_big, br_small = _bridge(big, ts, dev), _bridge(small, ts, dev)
+    h_big = br_big.sweep_handle(N, True, False)
+    h_small = br_small.sweep_handle(N, True, False)
+    key = oracle.split(oracle.PRNGKey(11), 2)[0]
+    for toy, br, h in ((small, br_small, h_small), (big, br_big, h_big)):
+        rng = np.random.default_rng(toy["du"])
+        x0 = rng.normal(size=toy["du"]).astype(np.float32)
+        bs = rng.integers(0, N, T + 1).astype(np.int32)
+        want = oracle.gibbs_kernel_lg(oracle_model_from(oracle, br), key, x0, toy["y0"], bs, N, True, False)
+        got = h.sweep(key, x0, toy["y0"], bs, use_graph=False)
+        _eq(_np(got[0]), want[0], "x0_next")
+        _eq(_np(got[1]), want[1], "us_star_next")
+
+
 def test_wide_batched_chains_match_single_chains(oracle, dev):
     toy = toy_gp(40)
     T, N, C = 6, 50, 3
