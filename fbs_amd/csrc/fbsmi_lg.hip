@@ -86,6 +86,10 @@ struct LgDev {
     int32_t* anc;                           // [N] ancestors of the current step (wide path)
     float* xiw;                             // [N][du] the NEXT step's noise, drawn by the previous launch (one-tile wide Gibbs)
     int lh_w, lh_j;                         // their depths
+    // two-launch step (N a power of two, 2..256 tiles): the searches walk the summation tree itself, so no cdf is written
+    float2* trW;                            // [nb][64]: per tile, heap-ordered nodes (sum of the node's left half, w at its midpoint)
+    float2* trWtop;                         // [nb][8]: the first three levels of every tile's heap, compact (LDS staging)
+    float* wfirst;                          // [nb]: w of every tile's first element
     float* scal;       // [16]: 0 lse, 1 w_max
     int32_t* As;       // [T][N] or null
     float* uss;        // [T+1][N][du] or null
@@ -123,6 +127,7 @@ struct LgDev {
 // depths of the compact heaps the cdf kernel publishes for k_lg_prop1
 constexpr int kHeapLevelsW = 11, kHeapSizeW = 1 << kHeapLevelsW;
 constexpr int kHeapLevelsJ = 8, kHeapSizeJ = 1 << kHeapLevelsJ;
+constexpr int kTreeNodes = 64;   // nodes of a tile's summation tree that are published (down to blocks of 8 leaves)
 
 __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
     const size_t N = d.N, T = d.T, D = d.D, du = d.du, dv = d.dv, nb = d.nb;
@@ -154,6 +159,11 @@ __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
     if (d.hpW) {
         d.hpW += (size_t)kHeapSizeW * c;
         d.hpJ += (size_t)kHeapSizeJ * c;
+    }
+    if (d.trW) {
+        d.trW += kTreeNodes * nb * c;
+        d.trWtop += 8 * nb * c;
+        d.wfirst += nb * c;
     }
     d.scal += 16 * (size_t)c;
     if (d.As) d.As += T * N * c;
@@ -423,13 +433,38 @@ __device__ __forceinline__ float block_max4(float m, float* lds4) {  // lds4 unt
 //        MODE 2: final, backward scanning (partials of w only).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float jprob_at(float w, float w_max, int N) { return (1.0f - w / w_max) / (float)N; }
+// the same value when N is a power of two and inv_n = 1 / N (scaling by a power of two is exact, and rounds the same way
+// into the subnormals)
+__device__ __forceinline__ float jprob_pow2(float w, float w_max, float inv_n) { return (1.0f - w / w_max) * inv_n; }
 
 __device__ __forceinline__ float fm_rest_at(float w, float w_k, bool is_k, int N) {
     if (w_k < 1.0f) return (is_k ? 0.0f : w) / (1.0f - w_k);
     return (float)(1.0 / (double)N);
 }
 
-template <int ITEMS, int MODE>
+// The node of the 256-leaf heap (root = 1) whose right half starts at leaf i >= 1, and the sum of that node's left
+// half out of leaf i's up-sweep record: leaf i with c trailing zero bits is the midpoint of the node of 2^(c+1) leaves
+// that contains it.
+__device__ __forceinline__ int tree_mid_node(int i) {
+    const int c = __builtin_ctz(i);
+    return (1 << (7 - c)) + (i >> (c + 1));
+}
+
+__device__ __forceinline__ float tree_left_sum(const TreePath p, int i) {   // by value: see below
+    // the lowest set bit of i picks the level; written as bit tests so that the record stays in registers (an index
+    // computed from ctz(i) becomes a load from scratch memory)
+    float v = p.ls[7];
+    v = (i & 64) ? p.ls[6] : v;
+    v = (i & 32) ? p.ls[5] : v;
+    v = (i & 16) ? p.ls[4] : v;
+    v = (i & 8) ? p.ls[3] : v;
+    v = (i & 4) ? p.ls[2] : v;
+    v = (i & 2) ? p.ls[1] : v;
+    v = (i & 1) ? p.ls[0] : v;
+    return v;
+}
+
+template <int ITEMS, int MODE, bool PUB = false>
 __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
     if (MODE == 0) { FBSMI_STAMP(2) }
@@ -447,6 +482,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
     const float w_max = fbsmi_expf(Mraw - lse);  // == max_i w_i: fbsmi_expf is monotone
     const float w_k = MODE == 1 ? fbsmi_expf(l_ref - lse) : 0.0f;
     float xw[ITEMS], xj[ITEMS];
+    const float inv_n = 1.0f / (float)d.N;   // PUB: N is a power of two, x / N == x * (1 / N) exactly
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int e = base + i;
@@ -456,16 +492,29 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
             const float ln = l[i] - lse;
             const float w = fbsmi_expf(ln);
             d.w[e] = w;
-            d.lwn[e] = ln;
+            if (MODE != 0) d.lwn[e] = ln;   // read back only after the final normalisation (view 1)
             if (d.lwss) d.lwss[(size_t)s * d.N + e] = ln;
             xw[i] = w;
-            if (MODE == 0) xj[i] = e == i_ref ? 0.0f : jprob_at(w, w_max, d.N);
+            if (MODE == 0) xj[i] = e == i_ref ? 0.0f : (PUB ? jprob_pow2(w, w_max, inv_n) : jprob_at(w, w_max, d.N));
             if (MODE == 1) xj[i] = fm_rest_at(w, w_k, e == i_ref, d.N);
         }
     }
     float s2[2] = {chunk_total<ITEMS>(xw), chunk_total<ITEMS>(xj)}, t2[2];
     TreePath p2[2];
     block_upsweep_n<2>(s2, p2, xch[2], t2);
+    if (PUB && ITEMS == 1) {   // the tile's part of the summation tree, for the tree-walking searches of k_lg_prop1t
+        __shared__ float2 heap[kTreeNodes];   // heap order permutes the threads: stage it, store coalesced
+        const int i = threadIdx.x;
+        const int h = i ? tree_mid_node(i) : 0;
+        if (h < kTreeNodes) heap[h] = make_float2(i ? tree_left_sum(p2[0], i) : 0.0f, xw[0]);
+        __syncthreads();
+        if (i < kTreeNodes) {
+            const float2 node = heap[i];
+            d.trW[(size_t)blockIdx.x * kTreeNodes + i] = node;
+            if (i < 8) d.trWtop[blockIdx.x * 8 + i] = node;
+            if (i == 0) d.wfirst[blockIdx.x] = node.y;
+        }
+    }
     if (threadIdx.x == 0) {
         if (MODE != 1) d.bsumw[blockIdx.x] = t2[0];
         if (MODE != 2) d.bsumJ[blockIdx.x] = t2[1];
@@ -829,6 +878,210 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
     float mx, sx;
     block_lse_partial<1>(lv, xch[0], xch[1], mx, sx);
     if (threadIdx.x == 0) {
+        d.bmax[blockIdx.x] = mx;
+        d.bsumexp[blockIdx.x] = sx;
+    }
+    FBSMI_STAMP(13)
+}
+
+// ------------------------------------------------------------------------------------------
+// The step in TWO launches (norm<PUB> -> k_lg_prop1t), for N a power of two with 2..256 tiles.
+//
+// The fixed-length bisection of searchsorted over the canonical cumsum IS a descent of the summation tree when N
+// is a power of two: at a node X = [lo, lo + sz) with prefix P in front of it, the probe is
+//      cdf[mid] = (P + sum(left half of X)) + x[mid]        (sz >= 4: leaf mid is the first leaf of the right half,
+//                                                            a left child whose own prefix is t = P + sum(left))
+//      cdf[mid] = E(X)                                      (sz == 2, and the closing one-leaf level)
+// and going left / right hands (P, E = t) / (P = t, E) to the child -- the two-value descent of fbsmi_device.h.  So
+// the searches need the tree's left-half sums and the leaves at the midpoints, never the cumsum itself: k_lg_norm
+// publishes them per tile (the records of its own up-sweep), this kernel builds the levels above the tiles from the
+// per-tile sums (which every workgroup re-reduces anyway), and the k_lg_cdf launch disappears from the step.
+//   J (workgroup-uniform): tile sums -> total -> J_prob[i*] -> the rebuilt tile of i* -> top tree with its sum
+//   substituted -> descent to a tile -> that tile's w fetched whole, its leaves and tree rebuilt in LDS -> descent.
+//   Cat(w) per slot: top levels + three levels of every tile in LDS, then (killed slots only) three levels from the
+//   tile's published heap in one round trip and the last four leaves of w in another.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool tree_walk(float2 nd, float q, float& P, float& E) {
+    const float t = P + nd.x;
+    const bool gl = q <= t + nd.y;
+    E = gl ? t : E;
+    P = gl ? P : t;
+    return gl;
+}
+
+template <int DMAX>
+__global__ void __launch_bounds__(kBlock) k_lg_prop1t(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float xch[5][4];
+    __shared__ float2 topW[kBlock], topJ[kBlock], tileJ[kBlock];
+    __shared__ __attribute__((aligned(16))) float2 midW[8 * kBlock];
+    FBSMI_STAMP(6)
+    const int N = d.N, nb = d.nb, tid = threadIdx.x;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], t0 = kt[6], t1 = kt[7];
+    const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
+    const int m = blockIdx.x * kBlock + tid;   // N is a multiple of the tile: every slot is live
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    // ---- round 0: everything addressable now
+    const float w_max = d.scal[1];
+    const float inv_n = 1.0f / (float)N;   // N is a power of two: x / N == x * inv_n exactly
+    const bool tl = tid < nb;
+    const float sw = tl ? d.bsumw[tid] : 0.0f;
+    const float sj = tl ? d.bsumJ[tid] : 0.0f;
+    const float wf = tl ? d.wfirst[tid] : 0.0f;
+    const int b_ref = i_ref / kBlock;
+    const float wr = d.w[b_ref * kBlock + tid];
+    float4 stg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + kBlock * k;
+        stg[k] = idx < 4 * nb ? reinterpret_cast<const float4*>(d.trWtop)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float uref[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) uref[r] = r < d.du ? up[(size_t)r * N + i_ref] : 0.0f;
+    const StepTables<DMAX> t = step_tables<DMAX>(d, s);
+    const float* v_prev = d.vs + (size_t)s * d.dv;
+    const float* v = d.vs + (size_t)(s + 1) * d.dv;
+    const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
+    const float u3 = __uint_as_float(kt[4]);
+    float xi[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) xi[r] = r < d.du ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r) : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + kBlock * k;
+        if (idx < 4 * nb) reinterpret_cast<float4*>(midW)[idx] = stg[k];
+    }
+    FBSMI_STAMP(7)
+    // ---- the levels above the tiles: sums of w, sums of J_prob with [i*] = 0 (one exchange)
+    const int g = tid ? tree_mid_node(tid) : 0;
+    float s2[2] = {sw, sj}, t2[2];
+    TreePath p2[2];
+    block_upsweep_n<2>(s2, p2, xch[0], t2);
+    const float last = t2[0];                      // == cdf[N - 1]
+    const float Ji = fmaxf(1.0f - t2[1], 0.0f);    // J_prob[i*] (resamplings.py:80-82)
+    if (tid) topW[g] = make_float2(tree_left_sum(p2[0], tid), wf);
+    // the tile that holds i*: its tree sum changes
+    float s1[1], t1s[1];
+    TreePath p1[1];
+    s1[0] = b_ref * kBlock + tid == i_ref ? Ji : jprob_pow2(wr, w_max, inv_n);
+    block_upsweep_n<1>(s1, p1, xch[2], t1s);
+    const float tile_ref = t1s[0];
+    s1[0] = tid == b_ref ? tile_ref : sj;
+    block_upsweep_n<1>(s1, p1, xch[3], t1s);
+    const float lastJ = t1s[0];                    // == cdfJ[N - 1]
+    if (tid) {
+        const float jf = tid * kBlock == i_ref ? Ji : (tl ? jprob_pow2(wf, w_max, inv_n) : 0.0f);
+        topJ[g] = make_float2(tree_left_sum(p1[0], tid), jf);
+    }
+    __syncthreads();
+    FBSMI_STAMP(8)
+    // ---- J = choice(key_3, N, (), p=J_prob) (resamplings.py:84): uniform over the workgroup.  The interval of the
+    // bisection is the node itself ([lo, hi) = the node's leaves), so the walk only keeps the heap index.
+    int J;
+    {
+        const float q = lastJ * (1.0f - u3);
+        int h = kBlock / nb;
+        float P = 0.0f, E = lastJ;
+        for (int l = nb; l > 1; l >>= 1) h = 2 * h + (tree_walk(topJ[h], q, P, E) ? 0 : 1);
+        const int lo0 = (h - kBlock) * kBlock;   // first slot of the tile the walk arrived at
+        const float wj = d.w[lo0 + tid];
+        s1[0] = lo0 + tid == i_ref ? Ji : jprob_pow2(wj, w_max, inv_n);
+        const float xj = s1[0];
+        block_upsweep_n<1>(s1, p1, xch[4], t1s);
+        if (tid) tileJ[g] = make_float2(tree_left_sum(p1[0], tid), xj);
+        __syncthreads();
+        h = 1;
+#pragma unroll
+        for (int l = 0; l < 7; ++l) h = 2 * h + (tree_walk(tileJ[h], q, P, E) ? 0 : 1);
+        {   // two leaves: the probe is E itself
+            const float tt = P + tileJ[h].x;
+            const bool gl = q <= E;
+            E = gl ? tt : E;
+            h = 2 * h + (gl ? 0 : 1);
+        }
+        const int leaf = lo0 + h - kBlock;
+        J = q <= E ? leaf : leaf + 1;
+    }
+    int shift = (j_ref - J) % N;   // roll by j - J (:85)
+    if (shift < 0) shift += N;
+    int src = m - shift;
+    if (src < 0) src += N;
+    FBSMI_STAMP(9)
+    // ---- round 2
+    const float ws = d.w[src];
+    float u[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) u[r] = r < d.du ? up[(size_t)r * N + src] : 0.0f;
+    const float u1 = uniform_at(a0, a1, (uint64_t)N, (uint64_t)src);
+    const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)src);
+    const float qK = last * (1.0f - u2);                                    // resamplings.py:73-74
+    float P = 0.0f, E = last;
+    int h = kBlock / nb;
+    for (int l = nb; l > 1; l >>= 1) h = 2 * h + (tree_walk(topW[h], qK, P, E) ? 0 : 1);
+    const int tile = h - kBlock;
+    h = 1;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) h = 2 * h + (tree_walk(midW[tile * 8 + h], qK, P, E) ? 0 : 1);
+    const bool killed = u1 * w_max >= ws;                                   // :71
+    FBSMI_STAMP(10)
+    // ---- rounds 3, 4 (killed slots only): nodes of 32, 16, 8 leaves from the tile's heap; then the last four leaves
+    int hi = 0;
+    if (killed) {
+        const float2* tr = d.trW + (size_t)tile * kTreeNodes;
+        const float2 n1 = tr[h];
+        const float4 n2 = *reinterpret_cast<const float4*>(tr + 2 * h);
+        const float4 n3a = *reinterpret_cast<const float4*>(tr + 4 * h);
+        const float4 n3b = *reinterpret_cast<const float4*>(tr + 4 * h + 2);
+        const bool g1 = tree_walk(n1, qK, P, E);
+        const bool g2 = tree_walk(g1 ? make_float2(n2.x, n2.y) : make_float2(n2.z, n2.w), qK, P, E);
+        const float4 n3 = g1 ? n3a : n3b;
+        const bool g3 = tree_walk(g2 ? make_float2(n3.x, n3.y) : make_float2(n3.z, n3.w), qK, P, E);
+        h = 8 * h + (g1 ? 0 : 4) + (g2 ? 0 : 2) + (g3 ? 0 : 1);        // a node of four leaves: 64 <= h < 128
+        const int lo = tile * kBlock + (h - 64) * 4;
+        const float4 w4 = *reinterpret_cast<const float4*>(d.w + lo);
+        const bool g4 = tree_walk(make_float2(w4.x + w4.y, w4.z), qK, P, E);
+        const float tt = P + (g4 ? w4.x : w4.z);
+        const bool g5 = qK <= E;                                         // two leaves: the probe is E itself
+        E = g5 ? tt : E;
+        const int leaf = lo + (g4 ? 0 : 2) + (g5 ? 0 : 1);
+        hi = qK <= E ? leaf : leaf + 1;
+    }
+    const bool pinned = m == j_ref;
+    const int a = pinned ? i_ref : (killed ? hi : src);                     // :86
+    FBSMI_STAMP(11)
+    // ---- round 5
+    if (killed && !pinned) {
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r)
+            if (r < d.du) u[r] = up[(size_t)r * N + a];
+    }
+    if (pinned) {
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) u[r] = uref[r];
+    }
+    float lv[1];
+    if (d.As) d.As[(size_t)s * N + m] = a;
+    // transition_sampler (gp_gibbs.py:120-122) and the pin of csmc.py:143
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) {
+        if (r < d.du) {
+            const float dr = drift_row<DMAX>(t, r, u, v_prev);
+            float x = (u[r] + dr * t.dt) + t.sd * xi[r];
+            if (pinned) x = ustar[r];
+            un[(size_t)r * N + m] = x;
+            if (d.uss) d.uss[((size_t)(s + 1) * N + m) * d.du + r] = x;
+        }
+    }
+    const float l = lg_loglik<DMAX>(t, u, v, v_prev);   // likelihood_logpdf on the gathered particle (csmc.py:145)
+    d.lw[m] = l;
+    lv[0] = l;
+    FBSMI_STAMP(12)
+    float mx, sx;
+    block_lse_partial<1>(lv, xch[0], xch[1], mx, sx);
+    if (tid == 0) {
         d.bmax[blockIdx.x] = mx;
         d.bsumexp[blockIdx.x] = sx;
     }
@@ -2156,6 +2409,7 @@ struct fbsmi_lg_sweep {
     int two_slot_prop = -1;  // FBSMI_TWO_SLOT_PROP=0|1: never / always (where applicable) k_lg_prop2; unset: by batch size
     bool step_launches = false;  // FBSMI_STEP_LAUNCHES=1: one launch per step also where one launch per sweep is possible
     bool generic_prop = false;  // FBSMI_GENERIC_PROP=1: k_lg_prop also for one slot per thread (timing experiments)
+    bool tree_step = true;  // FBSMI_TREE_STEP=0: keep the cdf launch also where the two-launch step applies
     int debug_mask = 7;  // FBSMI_DEBUG_STEP_MASK: bit0 norm, bit1 cdf, bit2 prop (timing experiments only)
     std::vector<hipEvent_t> prof_ev[kNumProfKernels];  // pairs (start, stop)
     double prof_us[kNumProfKernels] = {0, 0, 0};
@@ -2281,12 +2535,19 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
         if (d.wide) k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
         else k_lg_lwpart<<<gtile, kBlock, 0, st>>>(d);
     }
+    // enough workgroups that instruction issue, not latency, bounds the step (measured crossover: between four and six
+    // 256-slot workgroups per CU): two slots per thread, three Threefry calls instead of six
+    const bool two_slot = !d.wide && s->items == 1 && !s->generic_prop && d.N % (2 * kBlock) == 0 &&
+                          (s->two_slot_prop == 1 || (s->two_slot_prop < 0 && (int64_t)nb * d.C >= 5 * 256));
+    // N a power of two: the searches walk the summation tree, no cdf launch (k_lg_prop1t)
+    const bool tree = s->tree_step && d.trW && !s->generic_prop && !two_slot;
     for (int k = 0; !one_tile && k < d.T; ++k) {
         if (s->debug_mask & 1) {
             ProfScope p(s, 0, st);
-            LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 0><<<gtile, kBlock, 0, st>>>(d, k)));
+            if (tree) k_lg_norm<1, 0, true><<<gtile, kBlock, 0, st>>>(d, k);
+            else LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 0><<<gtile, kBlock, 0, st>>>(d, k)));
         }
-        if (s->debug_mask & 2) {
+        if ((s->debug_mask & 2) && !tree) {
             ProfScope p(s, 1, st);
             LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 0><<<gtile, kBlock, 0, st>>>(d, k)));
         }
@@ -2299,10 +2560,9 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                 else
                     k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
                 k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
-            } else if (s->items == 1 && !s->generic_prop && d.N % (2 * kBlock) == 0 &&
-                       (s->two_slot_prop == 1 || (s->two_slot_prop < 0 && (int64_t)nb * d.C >= 5 * 256))) {
-                // enough workgroups that instruction issue, not latency, bounds the step (measured crossover: between four and six
-                // 256-slot workgroups per CU): two slots per thread, three Threefry calls instead of six
+            } else if (tree) {
+                LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1t<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
+            } else if (two_slot) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
             } else if (s->items == 1 && !s->generic_prop) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
@@ -2426,6 +2686,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     if (const char* gp = getenv("FBSMI_GENERIC_PROP")) s->generic_prop = atoi(gp) != 0;
     if (const char* sl = getenv("FBSMI_STEP_LAUNCHES")) s->step_launches = atoi(sl) != 0;
     if (const char* sp = getenv("FBSMI_TWO_SLOT_PROP")) s->two_slot_prop = atoi(sp) != 0 ? 1 : 0;
+    if (const char* tp = getenv("FBSMI_TREE_STEP")) s->tree_step = atoi(tp) != 0;
     s->items = fbsmi_tile_items(d.N);  // one workgroup = one tile of the two-level logsumexp (include/fbsmi_math.h)
     const int maxd = m->du > m->dv ? m->du : m->dv;
     s->dmax = maxd <= 1 ? 1 : (maxd <= 2 ? 2 : (maxd <= 4 ? 4 : 16));   // du = dv = 1 (BASELINE configs 1, 2) has its own instantiation
@@ -2484,6 +2745,13 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         rc |= slab_request(s, &hp_map_dev, (size_t)N);
         rc |= slab_request(s, &d.hpW, C * (size_t)kHeapSizeW);
         rc |= slab_request(s, &d.hpJ, C * (size_t)kHeapSizeJ);
+    }
+    d.trW = d.trWtop = nullptr;
+    d.wfirst = nullptr;
+    if (s->items == 1 && !wide && (d.N & (d.N - 1)) == 0 && d.nb >= 2 && d.nb <= kBlock) {
+        rc |= slab_request(s, &d.trW, C * (size_t)kTreeNodes * d.nb);
+        rc |= slab_request(s, &d.trWtop, C * 8 * (size_t)d.nb);
+        rc |= slab_request(s, &d.wfirst, C * (size_t)d.nb);
     }
     rc |= slab_request(s, &d.bsumw, C * d.nb);
     rc |= slab_request(s, &d.bsumJ, C * d.nb);

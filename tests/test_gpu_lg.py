@@ -79,6 +79,10 @@ CASES = [
     (toy_4d, 256, 9, 1.0, True, False),       # the largest single-launch-per-step ensemble
     (toy_4d, 255, 9, 1.0, False, True),       # ... with explicit_final: N + 1 = 256 slots
     (toy_31, 257, 9, 1.0, True, False),       # just past it: three launches per step, two tiles
+    (toy_4d, 512, 12, 1.0, True, False),      # powers of two from two tiles up: the two-launch step (k_lg_prop1t)
+    (toy_31, 2048, 8, 1.0, False, False),     # ... with the stored path
+    (toy_2d, 4095, 8, 1.0, True, True),       # ... explicit_final: N + 1 = 4096 slots
+    (toy_2d, 32768, 6, 1.0, True, False),
 ]
 
 
@@ -379,6 +383,30 @@ def test_toy_filter_and_pmcmc_drivers(tmp_path, dev):
     z = (samples[:, 50:].reshape(-1, 20).mean(0) - gp_mean) / np.sqrt(np.diag(gp_cov))
     assert np.abs(z).max() < 2.5
     assert set(np.load(os.path.join(str(tmp_path), "pmcmc-0.005-const-200-666.npz")).files) == {"samples", "gp_mean", "gp_cov"}
+
+
+@pytest.mark.parametrize("tree", ["1", "0"])
+def test_tree_step_reference_indices_on_tile_edges(tree, oracle, dev, monkeypatch):
+    """The two-launch step (searches walk the summation tree) and the three-launch step it replaces (FBSMI_TREE_STEP=0)
+    with the reference path sitting on tile boundaries: first / last element of a tile, of the ensemble."""
+    monkeypatch.setenv("FBSMI_TREE_STEP", tree)
+    toy = toy_2d()
+    N, T = 1024, 12
+    ts = np.linspace(0, 1.0, T + 1)
+    br = _bridge(toy, ts, dev)
+    om = oracle_model_from(oracle, br)
+    x0 = np.array([0.3], np.float32)
+    bs = np.array([0, 256, 255, 1023, 512, 511, 0, 768, 1, 1023, 256, 257, 0], np.int32)
+    sweep = br.sweep_handle(N, True, False)
+    for trial in range(2):
+        key = oracle.split(oracle.PRNGKey(5 + trial), 2)[0]
+        want = oracle.gibbs_kernel_lg(om, key, x0, toy["y0"], bs, N, True, False, debug=True)
+        got = sweep.sweep(key, x0, toy["y0"], bs, use_graph=bool(trial))
+        v = sweep.views()
+        _eq(_np(v["us_T"]), want[4], "final particles")
+        _eq(_np(v["lw_T"]), want[5], "final log-weights")
+        for i, what in enumerate(("x0_next", "us_star_next", "bs_star_next", "acc")):
+            _eq(_np(got[i]), want[i], what)
 
 
 def test_two_slot_prop_kernel_matches_oracle(oracle, dev, monkeypatch):
