@@ -503,15 +503,12 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
     TreePath p2[2];
     block_upsweep_n<2>(s2, p2, xch[2], t2);
     if (PUB && ITEMS == 1) {   // the tile's part of the summation tree, for the tree-walking searches of k_lg_prop1t
-        __shared__ float2 heap[kTreeNodes];   // heap order permutes the threads: stage it, store coalesced
         const int i = threadIdx.x;
-        const int h = i ? tree_mid_node(i) : 0;
-        if (h < kTreeNodes) heap[h] = make_float2(i ? tree_left_sum(p2[0], i) : 0.0f, xw[0]);
-        __syncthreads();
-        if (i < kTreeNodes) {
-            const float2 node = heap[i];
-            d.trW[(size_t)blockIdx.x * kTreeNodes + i] = node;
-            if (i < 8) d.trWtop[blockIdx.x * 8 + i] = node;
+        if ((i & 3) == 0) {   // the midpoints of the nodes of 8 leaves and more: 64 threads, 16 per wave
+            const int h = i ? tree_mid_node(i) : 0;
+            const float2 node = make_float2(i ? tree_left_sum(p2[0], i) : 0.0f, xw[0]);
+            d.trW[(size_t)blockIdx.x * kTreeNodes + h] = node;
+            if (h < 8) d.trWtop[blockIdx.x * 8 + h] = node;
             if (i == 0) d.wfirst[blockIdx.x] = node.y;
         }
     }

@@ -90,8 +90,9 @@ def main():
                 wv = cols["SQ_WAVES"][k][0]
                 per = [cols[n].get(k, (0, 0))[0] / wv if wv else 0.0 for n in names[:-1]]
                 w.writerow([k, wv] + per + [cols["SQ_WAVES"][k][1]])
-                if "k_lg_prop" in k or "<1, 0>" in k:
-                    valu_json[k] = {"waves_per_launch": wv, "valu_per_wave": per[0], "salu_per_wave": per[1]}
+                if "k_lg_prop" in k or "<1, 0>" in k or "<1, 0, " in k:   # the step kernels (MODE 0)
+                    valu_json[k] = {"waves_per_launch": wv, "valu_per_wave": per[0], "salu_per_wave": per[1],
+                                    "launches": cols["SQ_WAVES"][k][1]}
     except SystemExit:
         pass
     cfg = bench["config"]
@@ -116,7 +117,8 @@ def main():
     if valu_json:
         pk = [kk for kk in valu_json if "k_lg_prop" in kk]
         if pk:
-            traffic["k_lg_prop_valu_insts_per_launch"] = valu_json[pk[0]]["valu_per_wave"] * valu_json[pk[0]]["waves_per_launch"]
+            top = max(pk, key=lambda kk: valu_json[kk]["launches"])
+            traffic["k_lg_prop_valu_insts_per_launch"] = valu_json[top]["valu_per_wave"] * valu_json[top]["waves_per_launch"]
         traffic["step_kernels_instruction_mix"] = valu_json
     json.dump(traffic, open(os.path.join(prof, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
