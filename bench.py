@@ -193,7 +193,8 @@ def main():
         # VALU issue roof: one wave64 instruction per CU per clock (4 SIMDs x 1 per 4 clocks), 256 CUs at ~2.4 GHz;
         # f64 instructions (the exp of the numeric spec) take two slots, so this is a lower bound on the occupancy
         valu_frac = (valu_insts / (256.0 * 2.4e3 * prop_us)) if (valu_insts and C == 4) else None
-        roofline = {"bound": "hbm", "kernel": "k_lg_prop (resample + gather + Euler-Maruyama + log-weight)",
+        roofline = {"bound": "hbm", "kernel": "k_lg_prop1t (tree-walking searches + resample + gather + Euler-Maruyama + log-weight)"
+                    if "cdf" not in kern else "k_lg_prop (resample + gather + Euler-Maruyama + log-weight)",
                     "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                     "traffic": traffic, "bytes_per_launch": prop_bytes, "avg_launch_us": prop_us,
                     "timing": "hipEvent pairs around each launch on the launch stream, net of the event overhead "
@@ -201,6 +202,8 @@ def main():
                     "event_overhead_us": c_ev, "raw_event_us": raw, "kernels_us": net,
                     "valu_issue_frac": valu_frac,
                     "whole_sweep_GBps": bpp["step"] * float(N) * T * C / (ms_per_step * 1e-3) / 1e9,
+                    "whole_step_frac": bpp["step"] * float(N) * T * C / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "launches_per_step": len(kern),
                     "note": "working set per step is a few MB (cache-resident) and the kernel is latency- then "
                             "VALU-bound (in-kernel Threefry + erf_inv), not HBM-bound: see DESIGN.md"}
         single = None

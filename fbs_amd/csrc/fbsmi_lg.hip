@@ -906,14 +906,148 @@ __device__ __forceinline__ bool tree_walk(float2 nd, float q, float& P, float& E
     return gl;
 }
 
+// what a workgroup of the two-launch step loads at entry for the trees (issued before the noise draws)
+struct TreeEntry {
+    float sw, sj, wf, wr;   // tile `tid`: sum of w, sum of J_prob ([i*] = 0), w of its first element; w of the tile of i*
+    float4 stg[4];          // this thread's part of trWtop
+};
+
+__device__ __forceinline__ TreeEntry tree_entry_loads(const LgDev& d, int i_ref) {
+    const int tid = threadIdx.x, nb = d.nb;
+    TreeEntry e;
+    const bool tl = tid < nb;
+    e.sw = tl ? d.bsumw[tid] : 0.0f;
+    e.sj = tl ? d.bsumJ[tid] : 0.0f;
+    e.wf = tl ? d.wfirst[tid] : 0.0f;
+    e.wr = d.w[(i_ref / kBlock) * kBlock + tid];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + kBlock * k;
+        e.stg[k] = idx < 4 * nb ? reinterpret_cast<const float4*>(d.trWtop)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return e;
+}
+
+// LDS of the tree walks: heaps over the 256 tile leaves for w and J_prob, the heap of the tile J falls in, and the
+// first three levels of every tile's w heap
+struct TreeLds {
+    float xch[5][4];
+    float2 topW[kBlock], topJ[kBlock], tileJ[kBlock];
+    __attribute__((aligned(16))) float2 midW[8 * kBlock];
+};
+
+// Builds the heaps and finds J = choice(key_3, N, (), p=J_prob) (resamplings.py:84), the same in every thread;
+// `last` = cdf[N - 1].  Ends with every heap visible to the workgroup.
+__device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, TreeLds& L, int i_ref, float u3, float w_max,
+                                          float inv_n, float& last) {
+    const int nb = d.nb, tid = threadIdx.x;
+    const int b_ref = i_ref / kBlock;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + kBlock * k;
+        if (idx < 4 * nb) reinterpret_cast<float4*>(L.midW)[idx] = e.stg[k];
+    }
+    // ---- the levels above the tiles: sums of w, sums of J_prob with [i*] = 0 (one exchange)
+    const int g = tid ? tree_mid_node(tid) : 0;
+    float s2[2] = {e.sw, e.sj}, t2[2];
+    TreePath p2[2];
+    block_upsweep_n<2>(s2, p2, L.xch[0], t2);
+    last = t2[0];                                  // == cdf[N - 1]
+    const float Ji = fmaxf(1.0f - t2[1], 0.0f);    // J_prob[i*] (resamplings.py:80-82)
+    if (tid) L.topW[g] = make_float2(tree_left_sum(p2[0], tid), e.wf);
+    // the tile that holds i*: its tree sum changes
+    float s1[1], t1s[1];
+    TreePath p1[1];
+    s1[0] = b_ref * kBlock + tid == i_ref ? Ji : jprob_pow2(e.wr, w_max, inv_n);
+    block_upsweep_n<1>(s1, p1, L.xch[2], t1s);
+    const float tile_ref = t1s[0];
+    s1[0] = tid == b_ref ? tile_ref : e.sj;
+    block_upsweep_n<1>(s1, p1, L.xch[3], t1s);
+    const float lastJ = t1s[0];                    // == cdfJ[N - 1]
+    if (tid) {
+        const float jf = tid * kBlock == i_ref ? Ji : (tid < nb ? jprob_pow2(e.wf, w_max, inv_n) : 0.0f);
+        L.topJ[g] = make_float2(tree_left_sum(p1[0], tid), jf);
+    }
+    __syncthreads();
+    // ---- the walk for J.  The interval of the bisection is the node itself ([lo, hi) = the node's leaves), so the
+    // walk only keeps the heap index.
+    const float q = lastJ * (1.0f - u3);
+    int h = kBlock / nb;
+    float P = 0.0f, E = lastJ;
+    for (int l = nb; l > 1; l >>= 1) h = 2 * h + (tree_walk(L.topJ[h], q, P, E) ? 0 : 1);
+    const int lo0 = (h - kBlock) * kBlock;   // first slot of the tile the walk arrived at
+    const float wj = d.w[lo0 + tid];
+    s1[0] = lo0 + tid == i_ref ? Ji : jprob_pow2(wj, w_max, inv_n);
+    const float xj = s1[0];
+    block_upsweep_n<1>(s1, p1, L.xch[4], t1s);
+    if (tid) L.tileJ[g] = make_float2(tree_left_sum(p1[0], tid), xj);
+    __syncthreads();
+    h = 1;
+#pragma unroll
+    for (int l = 0; l < 7; ++l) h = 2 * h + (tree_walk(L.tileJ[h], q, P, E) ? 0 : 1);
+    {   // two leaves: the probe is E itself
+        const float tt = P + L.tileJ[h].x;
+        const bool gl = q <= E;
+        E = gl ? tt : E;
+        h = 2 * h + (gl ? 0 : 1);
+    }
+    const int leaf = lo0 + h - kBlock;
+    return q <= E ? leaf : leaf + 1;
+}
+
+// Cat(w) search, LDS part: down to a node of 32 leaves (heap index h of tile `tile`)
+__device__ __forceinline__ void tree_search_lds(const TreeLds& L, int nb, float q, float& P, float& E, int& tile, int& h) {
+    h = kBlock / nb;
+    for (int l = nb; l > 1; l >>= 1) h = 2 * h + (tree_walk(L.topW[h], q, P, E) ? 0 : 1);
+    tile = h - kBlock;
+    h = 1;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) h = 2 * h + (tree_walk(L.midW[tile * 8 + h], q, P, E) ? 0 : 1);
+}
+
+// ... the rest: nodes of 32, 16, 8 leaves from the tile's published heap in one round trip, the last four leaves of
+// w in another.  K searches in lockstep (all loads of a round issued before the first is used); `on` = false: no
+// loads, result untouched.
+struct TreeRound {   // the seven nodes of one three-level round, as scalars (selects between vector loads end up in scratch)
+    float s1, y1, s2l, y2l, s2r, y2r, s3a, y3a, s3b, y3b, s3c, y3c, s3d, y3d;
+};
+
+__device__ __forceinline__ TreeRound tree_round_load(const LgDev& d, int tile, int h) {
+    const float2* tr = d.trW + (size_t)tile * kTreeNodes;
+    const float2 n1 = tr[h];
+    const float4 n2 = *reinterpret_cast<const float4*>(tr + 2 * h);
+    const float4 n3a = *reinterpret_cast<const float4*>(tr + 4 * h);
+    const float4 n3b = *reinterpret_cast<const float4*>(tr + 4 * h + 2);
+    return TreeRound{n1.x, n1.y, n2.x, n2.y, n2.z, n2.w, n3a.x, n3a.y, n3a.z, n3a.w, n3b.x, n3b.y, n3b.z, n3b.w};
+}
+
+// three levels; returns the first of the four leaves the walk arrived at
+__device__ __forceinline__ int tree_round_walk(const TreeRound r, int tile, int h, float q, float& P, float& E) {
+    const bool g1 = tree_walk(make_float2(r.s1, r.y1), q, P, E);
+    const bool g2 = tree_walk(make_float2(g1 ? r.s2l : r.s2r, g1 ? r.y2l : r.y2r), q, P, E);
+    const float s3 = g1 ? (g2 ? r.s3a : r.s3b) : (g2 ? r.s3c : r.s3d);
+    const float y3 = g1 ? (g2 ? r.y3a : r.y3b) : (g2 ? r.y3c : r.y3d);
+    const bool g3 = tree_walk(make_float2(s3, y3), q, P, E);
+    const int h4 = 8 * h + (g1 ? 0 : 4) + (g2 ? 0 : 2) + (g3 ? 0 : 1);   // a node of four leaves: 64 <= h4 < 128
+    return tile * kBlock + (h4 - 64) * 4;
+}
+
+// the last four leaves (w4 = w[lo .. lo + 3]) and the closing one-leaf level
+__device__ __forceinline__ int tree_leaves_walk(float4 w4, int lo, float q, float P, float E) {
+    const bool g4 = tree_walk(make_float2(w4.x + w4.y, w4.z), q, P, E);
+    const float tt = P + (g4 ? w4.x : w4.z);
+    const bool g5 = q <= E;                                                  // two leaves: the probe is E itself
+    const float e1 = g5 ? tt : E;
+    const int leaf = lo + (g4 ? 0 : 2) + (g5 ? 0 : 1);
+    return q <= e1 ? leaf : leaf + 1;
+}
+
 template <int DMAX>
 __global__ void __launch_bounds__(kBlock) k_lg_prop1t(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
-    __shared__ float xch[5][4];
-    __shared__ float2 topW[kBlock], topJ[kBlock], tileJ[kBlock];
-    __shared__ __attribute__((aligned(16))) float2 midW[8 * kBlock];
+    __shared__ TreeLds L;
     FBSMI_STAMP(6)
-    const int N = d.N, nb = d.nb, tid = threadIdx.x;
+    const int N = d.N, tid = threadIdx.x;
     const uint32_t* kt = d.keytab + 8 * s;
     const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], t0 = kt[6], t1 = kt[7];
     const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
@@ -923,18 +1057,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1t(LgDev dd, int s) {
     // ---- round 0: everything addressable now
     const float w_max = d.scal[1];
     const float inv_n = 1.0f / (float)N;   // N is a power of two: x / N == x * inv_n exactly
-    const bool tl = tid < nb;
-    const float sw = tl ? d.bsumw[tid] : 0.0f;
-    const float sj = tl ? d.bsumJ[tid] : 0.0f;
-    const float wf = tl ? d.wfirst[tid] : 0.0f;
-    const int b_ref = i_ref / kBlock;
-    const float wr = d.w[b_ref * kBlock + tid];
-    float4 stg[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = tid + kBlock * k;
-        stg[k] = idx < 4 * nb ? reinterpret_cast<const float4*>(d.trWtop)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    const TreeEntry te = tree_entry_loads(d, i_ref);
     float uref[DMAX];
 #pragma unroll
     for (int r = 0; r < DMAX; ++r) uref[r] = r < d.du ? up[(size_t)r * N + i_ref] : 0.0f;
@@ -946,62 +1069,9 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1t(LgDev dd, int s) {
     float xi[DMAX];
 #pragma unroll
     for (int r = 0; r < DMAX; ++r) xi[r] = r < d.du ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r) : 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = tid + kBlock * k;
-        if (idx < 4 * nb) reinterpret_cast<float4*>(midW)[idx] = stg[k];
-    }
     FBSMI_STAMP(7)
-    // ---- the levels above the tiles: sums of w, sums of J_prob with [i*] = 0 (one exchange)
-    const int g = tid ? tree_mid_node(tid) : 0;
-    float s2[2] = {sw, sj}, t2[2];
-    TreePath p2[2];
-    block_upsweep_n<2>(s2, p2, xch[0], t2);
-    const float last = t2[0];                      // == cdf[N - 1]
-    const float Ji = fmaxf(1.0f - t2[1], 0.0f);    // J_prob[i*] (resamplings.py:80-82)
-    if (tid) topW[g] = make_float2(tree_left_sum(p2[0], tid), wf);
-    // the tile that holds i*: its tree sum changes
-    float s1[1], t1s[1];
-    TreePath p1[1];
-    s1[0] = b_ref * kBlock + tid == i_ref ? Ji : jprob_pow2(wr, w_max, inv_n);
-    block_upsweep_n<1>(s1, p1, xch[2], t1s);
-    const float tile_ref = t1s[0];
-    s1[0] = tid == b_ref ? tile_ref : sj;
-    block_upsweep_n<1>(s1, p1, xch[3], t1s);
-    const float lastJ = t1s[0];                    // == cdfJ[N - 1]
-    if (tid) {
-        const float jf = tid * kBlock == i_ref ? Ji : (tl ? jprob_pow2(wf, w_max, inv_n) : 0.0f);
-        topJ[g] = make_float2(tree_left_sum(p1[0], tid), jf);
-    }
-    __syncthreads();
-    FBSMI_STAMP(8)
-    // ---- J = choice(key_3, N, (), p=J_prob) (resamplings.py:84): uniform over the workgroup.  The interval of the
-    // bisection is the node itself ([lo, hi) = the node's leaves), so the walk only keeps the heap index.
-    int J;
-    {
-        const float q = lastJ * (1.0f - u3);
-        int h = kBlock / nb;
-        float P = 0.0f, E = lastJ;
-        for (int l = nb; l > 1; l >>= 1) h = 2 * h + (tree_walk(topJ[h], q, P, E) ? 0 : 1);
-        const int lo0 = (h - kBlock) * kBlock;   // first slot of the tile the walk arrived at
-        const float wj = d.w[lo0 + tid];
-        s1[0] = lo0 + tid == i_ref ? Ji : jprob_pow2(wj, w_max, inv_n);
-        const float xj = s1[0];
-        block_upsweep_n<1>(s1, p1, xch[4], t1s);
-        if (tid) tileJ[g] = make_float2(tree_left_sum(p1[0], tid), xj);
-        __syncthreads();
-        h = 1;
-#pragma unroll
-        for (int l = 0; l < 7; ++l) h = 2 * h + (tree_walk(tileJ[h], q, P, E) ? 0 : 1);
-        {   // two leaves: the probe is E itself
-            const float tt = P + tileJ[h].x;
-            const bool gl = q <= E;
-            E = gl ? tt : E;
-            h = 2 * h + (gl ? 0 : 1);
-        }
-        const int leaf = lo0 + h - kBlock;
-        J = q <= E ? leaf : leaf + 1;
-    }
+    float last;
+    const int J = tree_build(d, te, L, i_ref, u3, w_max, inv_n, last);
     int shift = (j_ref - J) % N;   // roll by j - J (:85)
     if (shift < 0) shift += N;
     int src = m - shift;
@@ -1014,43 +1084,23 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1t(LgDev dd, int s) {
     for (int r = 0; r < DMAX; ++r) u[r] = r < d.du ? up[(size_t)r * N + src] : 0.0f;
     const float u1 = uniform_at(a0, a1, (uint64_t)N, (uint64_t)src);
     const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)src);
-    const float qK = last * (1.0f - u2);                                    // resamplings.py:73-74
-    float P = 0.0f, E = last;
-    int h = kBlock / nb;
-    for (int l = nb; l > 1; l >>= 1) h = 2 * h + (tree_walk(topW[h], qK, P, E) ? 0 : 1);
-    const int tile = h - kBlock;
-    h = 1;
-#pragma unroll
-    for (int l = 0; l < 3; ++l) h = 2 * h + (tree_walk(midW[tile * 8 + h], qK, P, E) ? 0 : 1);
-    const bool killed = u1 * w_max >= ws;                                   // :71
+    const float qK[1] = {last * (1.0f - u2)};                               // resamplings.py:73-74
+    float P[1] = {0.0f}, E[1] = {last};
+    int tile[1], h[1], hi[1] = {0};
+    tree_search_lds(L, d.nb, qK[0], P[0], E[0], tile[0], h[0]);
+    const bool killed[1] = {u1 * w_max >= ws};                              // :71
     FBSMI_STAMP(10)
-    // ---- rounds 3, 4 (killed slots only): nodes of 32, 16, 8 leaves from the tile's heap; then the last four leaves
-    int hi = 0;
-    if (killed) {
-        const float2* tr = d.trW + (size_t)tile * kTreeNodes;
-        const float2 n1 = tr[h];
-        const float4 n2 = *reinterpret_cast<const float4*>(tr + 2 * h);
-        const float4 n3a = *reinterpret_cast<const float4*>(tr + 4 * h);
-        const float4 n3b = *reinterpret_cast<const float4*>(tr + 4 * h + 2);
-        const bool g1 = tree_walk(n1, qK, P, E);
-        const bool g2 = tree_walk(g1 ? make_float2(n2.x, n2.y) : make_float2(n2.z, n2.w), qK, P, E);
-        const float4 n3 = g1 ? n3a : n3b;
-        const bool g3 = tree_walk(g2 ? make_float2(n3.x, n3.y) : make_float2(n3.z, n3.w), qK, P, E);
-        h = 8 * h + (g1 ? 0 : 4) + (g2 ? 0 : 2) + (g3 ? 0 : 1);        // a node of four leaves: 64 <= h < 128
-        const int lo = tile * kBlock + (h - 64) * 4;
-        const float4 w4 = *reinterpret_cast<const float4*>(d.w + lo);
-        const bool g4 = tree_walk(make_float2(w4.x + w4.y, w4.z), qK, P, E);
-        const float tt = P + (g4 ? w4.x : w4.z);
-        const bool g5 = qK <= E;                                         // two leaves: the probe is E itself
-        E = g5 ? tt : E;
-        const int leaf = lo + (g4 ? 0 : 2) + (g5 ? 0 : 1);
-        hi = qK <= E ? leaf : leaf + 1;
+    // ---- rounds 3, 4 (killed slots only)
+    if (killed[0]) {
+        const TreeRound rd = tree_round_load(d, tile[0], h[0]);
+        const int lo = tree_round_walk(rd, tile[0], h[0], qK[0], P[0], E[0]);
+        hi[0] = tree_leaves_walk(*reinterpret_cast<const float4*>(d.w + lo), lo, qK[0], P[0], E[0]);
     }
     const bool pinned = m == j_ref;
-    const int a = pinned ? i_ref : (killed ? hi : src);                     // :86
+    const int a = pinned ? i_ref : (killed[0] ? hi[0] : src);               // :86
     FBSMI_STAMP(11)
     // ---- round 5
-    if (killed && !pinned) {
+    if (killed[0] && !pinned) {
 #pragma unroll
         for (int r = 0; r < DMAX; ++r)
             if (r < d.du) u[r] = up[(size_t)r * N + a];
@@ -1077,12 +1127,157 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1t(LgDev dd, int s) {
     lv[0] = l;
     FBSMI_STAMP(12)
     float mx, sx;
-    block_lse_partial<1>(lv, xch[0], xch[1], mx, sx);
+    block_lse_partial<1>(lv, L.xch[0], L.xch[1], mx, sx);
     if (tid == 0) {
         d.bmax[blockIdx.x] = mx;
         d.bsumexp[blockIdx.x] = sx;
     }
     FBSMI_STAMP(13)
+}
+
+// The two-launch step with TWO slots per thread (see k_lg_prop2 below for the pairing): the trees, J and the
+// staging are built once per 512 slots.
+template <int DMAX>
+__global__ void __launch_bounds__(kBlock) k_lg_prop2t(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ TreeLds L;
+    __shared__ float xch2[2][8];
+    const int N = d.N, half = N >> 1, tid = threadIdx.x;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], t0 = kt[6], t1 = kt[7];
+    const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
+    const int mA = blockIdx.x * kBlock + tid;   // < N/2
+    const int m[2] = {mA, mA + half};
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    // ---- round 0
+    const float w_max = d.scal[1];
+    const float inv_n = 1.0f / (float)N;
+    const TreeEntry te = tree_entry_loads(d, i_ref);
+    float uref[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) uref[r] = r < d.du ? up[(size_t)r * N + i_ref] : 0.0f;
+    const StepTables<DMAX> t = step_tables<DMAX>(d, s);
+    const float* v_prev = d.vs + (size_t)s * d.dv;
+    const float* v = d.vs + (size_t)(s + 1) * d.dv;
+    const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
+    const float u3 = __uint_as_float(kt[4]);
+    float xi[2][DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) {
+        xi[0][r] = 0.0f;
+        xi[1][r] = 0.0f;
+        if (r < d.du) {   // element mA * du + r is in the first half of the draw, its partner belongs to slot mA + N/2
+            uint32_t lo_, hi_;
+            random_bits_pair(t0, t1, (uint64_t)N * d.du, (uint64_t)mA * d.du + r, lo_, hi_);
+            xi[0][r] = fbsmi_bits_to_normal(lo_);
+            xi[1][r] = fbsmi_bits_to_normal(hi_);
+        }
+    }
+    float last;
+    const int J = tree_build(d, te, L, i_ref, u3, w_max, inv_n, last);
+    int shift = (j_ref - J) % N;
+    if (shift < 0) shift += N;
+    int src[2];
+    src[0] = mA - shift;
+    if (src[0] < 0) src[0] += N;
+    const bool a_low = src[0] < half;          // the two sources are N/2 apart too
+    src[1] = a_low ? src[0] + half : src[0] - half;
+    const int pbase = a_low ? src[0] : src[1];
+    // ---- round 2
+    float ws[2], u[2][DMAX];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        ws[h2] = d.w[src[h2]];
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) u[h2][r] = r < d.du ? up[(size_t)r * N + src[h2]] : 0.0f;
+    }
+    uint32_t k_lo, k_hi, r_lo, r_hi;
+    random_bits_pair(a0, a1, (uint64_t)N, (uint64_t)pbase, k_lo, k_hi);
+    random_bits_pair(b0, b1, (uint64_t)N, (uint64_t)pbase, r_lo, r_hi);
+    const float u1[2] = {fbsmi_bits_to_unit(a_low ? k_lo : k_hi), fbsmi_bits_to_unit(a_low ? k_hi : k_lo)};
+    const float u2[2] = {fbsmi_bits_to_unit(a_low ? r_lo : r_hi), fbsmi_bits_to_unit(a_low ? r_hi : r_lo)};
+    const float qK[2] = {last * (1.0f - u2[0]), last * (1.0f - u2[1])};    // resamplings.py:73-74
+    float P[2] = {0.0f, 0.0f}, E[2] = {last, last};
+    int tile[2], h[2], hi[2] = {0, 0};
+    {   // the two LDS walks in lockstep
+        const int nb = d.nb;
+        int h0 = kBlock / nb, h1 = h0;
+        for (int l = nb; l > 1; l >>= 1) {
+            const float2 n0 = L.topW[h0], n1 = L.topW[h1];
+            h0 = 2 * h0 + (tree_walk(n0, qK[0], P[0], E[0]) ? 0 : 1);
+            h1 = 2 * h1 + (tree_walk(n1, qK[1], P[1], E[1]) ? 0 : 1);
+        }
+        tile[0] = h0 - kBlock;
+        tile[1] = h1 - kBlock;
+        h0 = h1 = 1;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const float2 n0 = L.midW[tile[0] * 8 + h0], n1 = L.midW[tile[1] * 8 + h1];
+            h0 = 2 * h0 + (tree_walk(n0, qK[0], P[0], E[0]) ? 0 : 1);
+            h1 = 2 * h1 + (tree_walk(n1, qK[1], P[1], E[1]) ? 0 : 1);
+        }
+        h[0] = h0;
+        h[1] = h1;
+    }
+    const bool killed[2] = {u1[0] * w_max >= ws[0], u1[1] * w_max >= ws[1]};   // :71
+    // ---- rounds 3, 4
+    {   // both searches in lockstep: the loads of a round are issued before the first is used
+        TreeRound rd0{}, rd1{};
+        if (killed[0]) rd0 = tree_round_load(d, tile[0], h[0]);
+        if (killed[1]) rd1 = tree_round_load(d, tile[1], h[1]);
+        int lo0 = 0, lo1 = 0;
+        float4 w40 = make_float4(0.f, 0.f, 0.f, 0.f), w41 = w40;
+        if (killed[0]) {
+            lo0 = tree_round_walk(rd0, tile[0], h[0], qK[0], P[0], E[0]);
+            w40 = *reinterpret_cast<const float4*>(d.w + lo0);
+        }
+        if (killed[1]) {
+            lo1 = tree_round_walk(rd1, tile[1], h[1], qK[1], P[1], E[1]);
+            w41 = *reinterpret_cast<const float4*>(d.w + lo1);
+        }
+        if (killed[0]) hi[0] = tree_leaves_walk(w40, lo0, qK[0], P[0], E[0]);
+        if (killed[1]) hi[1] = tree_leaves_walk(w41, lo1, qK[1], P[1], E[1]);
+    }
+    float lnew[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        const bool pinned = m[h2] == j_ref;
+        const int a = pinned ? i_ref : (killed[h2] ? hi[h2] : src[h2]);     // :86
+        // ---- round 5
+        if (killed[h2] && !pinned) {
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r)
+                if (r < d.du) u[h2][r] = up[(size_t)r * N + a];
+        }
+        if (pinned) {
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) u[h2][r] = uref[r];
+        }
+        if (d.As) d.As[(size_t)s * N + m[h2]] = a;
+        // transition_sampler (gp_gibbs.py:120-122) and the pin of csmc.py:143
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) {
+            if (r < d.du) {
+                const float dr = drift_row<DMAX>(t, r, u[h2], v_prev);
+                float x = (u[h2][r] + dr * t.dt) + t.sd * xi[h2][r];
+                if (pinned) x = ustar[r];
+                un[(size_t)r * N + m[h2]] = x;
+                if (d.uss) d.uss[((size_t)(s + 1) * N + m[h2]) * d.du + r] = x;
+            }
+        }
+        lnew[h2] = lg_loglik<DMAX>(t, u[h2], v, v_prev);   // likelihood_logpdf on the gathered particle (csmc.py:145)
+        d.lw[m[h2]] = lnew[h2];
+    }
+    float mxA, sxA, mxB, sxB;
+    block_lse_partial2(lnew[0], lnew[1], xch2[0], xch2[1], mxA, sxA, mxB, sxB);
+    if (tid == 0) {
+        const int tb = blockIdx.x + (d.nb >> 1);
+        d.bmax[blockIdx.x] = mxA;
+        d.bsumexp[blockIdx.x] = sxA;
+        d.bmax[tb] = mxB;
+        d.bsumexp[tb] = sxB;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2537,7 +2732,7 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     const bool two_slot = !d.wide && s->items == 1 && !s->generic_prop && d.N % (2 * kBlock) == 0 &&
                           (s->two_slot_prop == 1 || (s->two_slot_prop < 0 && (int64_t)nb * d.C >= 5 * 256));
     // N a power of two: the searches walk the summation tree, no cdf launch (k_lg_prop1t)
-    const bool tree = s->tree_step && d.trW && !s->generic_prop && !two_slot;
+    const bool tree = s->tree_step && d.trW && !s->generic_prop;
     for (int k = 0; !one_tile && k < d.T; ++k) {
         if (s->debug_mask & 1) {
             ProfScope p(s, 0, st);
@@ -2557,6 +2752,8 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                 else
                     k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
                 k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
+            } else if (tree && two_slot) {
+                LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2t<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
             } else if (tree) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1t<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
             } else if (two_slot) {

@@ -409,11 +409,14 @@ def test_tree_step_reference_indices_on_tile_edges(tree, oracle, dev, monkeypatc
             _eq(_np(got[i]), want[i], what)
 
 
-def test_two_slot_prop_kernel_matches_oracle(oracle, dev, monkeypatch):
-    """k_lg_prop2 (two slots per thread, N/2 apart: the kill-test / redraw / noise draws of both slots from three
-    Threefry calls) is chosen for big batches; forced here on small ones.  Bit-exact like every other variant."""
+@pytest.mark.parametrize("tree", ["1", "0"])
+def test_two_slot_prop_kernel_matches_oracle(tree, oracle, dev, monkeypatch):
+    """k_lg_prop2 / k_lg_prop2t (two slots per thread, N/2 apart: the kill-test / redraw / noise draws of both slots
+    from three Threefry calls) are chosen for big batches; forced here on small ones, with the two-launch step (powers
+    of two) and without.  Bit-exact like every other variant."""
     monkeypatch.setenv("FBSMI_TWO_SLOT_PROP", "1")
-    for toy, N, T, C in ((toy_2d, 1024, 40, 1), (toy_4d, 512, 12, 3), (toy_31, 2048, 6, 2)):
+    monkeypatch.setenv("FBSMI_TREE_STEP", tree)
+    for toy, N, T, C in ((toy_2d, 1024, 40, 1), (toy_4d, 512, 12, 3), (toy_31, 2048, 6, 2), (toy_2d, 1536, 8, 2)):
         toy_ = toy()
         ts = np.linspace(0, 1.0, T + 1)
         br = _bridge(toy_, ts, dev)
