@@ -4,8 +4,8 @@
 // sampler (fbs/sdes/linear.py:190-221) and the three model closures of
 // experiments/toy/gp_gibbs.py:120-135 folded in, entirely on the device.
 //
-// One SMC step has three grid-wide dependency levels, each a kernel (kernel boundaries are the
-// cheapest grid-wide synchronisation on MI355X, ~1.5 us):
+// The general SMC step is three kernels (kernel boundaries are the cheapest grid-wide synchronisation on
+// MI355X, ~1.7 us):
 //
 //   norm  : lse from the (max, sumexp) pairs the previous kernel published per workgroup (two-level
 //           logsumexp, include/fbsmi_math.h); w = exp(lw - lse);
@@ -18,7 +18,7 @@
 //           log-weight, per-workgroup (max, sumexp)                      [resamplings.py:71-86, csmc.py:140-145]
 //
 // Particle state is structure-of-arrays u[r][p] so that every per-slot access is coalesced.
-// A whole sweep (3T + ~10 launches) is captured once into a hipGraph and replayed.
+// A whole sweep (2T + ~10 launches when N is a power of two, 3T + ~10 otherwise) is captured once into a hipGraph and replayed.
 //
 // Variants of the step, chosen at handle creation (all bit-identical to the oracle):
 //   N <= 256 (one logsumexp tile, one workgroup)   : lgw_pre_body does norm + cdf + searches in LDS;
@@ -27,6 +27,8 @@
 //       (k_lgw_gemm: v_mfma_f32_16x16x4_f32 == ascending fmaf chain); N <= 256: one launch per step with the
 //       prologue fused in; N > 256: norm -> cdf -> k_lgw_anc -> k_lgw_gemm | k_lgw_gemm_fat -> k_lgw_lse
 //   N > 131072                                      : 4 / 16 slots per thread (k_lg_prop<ITEMS>)
+//   N a power of two, 512 .. 65536                  : TWO kernels per step -- the bisection over the canonical cumsum is a
+//       descent of the summation tree, so norm publishes tree nodes and k_lg_prop1t / k_lg_prop2t walk them; no cdf
 #include <hip/hip_runtime.h>
 
 #include <cmath>
