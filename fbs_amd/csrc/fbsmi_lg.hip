@@ -938,6 +938,8 @@ struct TreeLds {
     __attribute__((aligned(16))) float2 midW[8 * kBlock];
 };
 
+constexpr int kTreeBuildBarriers = 6;   // __syncthreads() executed by tree_build (four up-sweep exchanges, two explicit)
+
 // Builds the heaps and finds J = choice(key_3, N, (), p=J_prob) (resamplings.py:84), the same in every thread;
 // `last` = cdf[N - 1].  Ends with every heap visible to the workgroup.
 __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, TreeLds& L, int i_ref, float u3, float w_max,
@@ -1044,22 +1046,29 @@ __device__ __forceinline__ int tree_leaves_walk(float4 w4, int lo, float q, floa
     return q <= e1 ? leaf : leaf + 1;
 }
 
-template <int DMAX>
-__global__ void __launch_bounds__(kBlock) k_lg_prop1t(LgDev dd, int s) {
+// HALVES = 2: a workgroup of 512 threads owns two adjacent tiles; its first half builds the trees and finds J (the
+// other four waves wait at the barriers instead of repeating ~450 instructions each), then every thread does its slot.
+template <int DMAX, int HALVES>
+__global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ TreeLds L;
+    __shared__ float part[2][8];
+    __shared__ int Jsh;
+    __shared__ float lastsh;
     FBSMI_STAMP(6)
-    const int N = d.N, tid = threadIdx.x;
+    const int N = d.N, tid = threadIdx.x & (kBlock - 1), half = threadIdx.x / kBlock;
+    const int tileb = blockIdx.x * HALVES + half;
     const uint32_t* kt = d.keytab + 8 * s;
     const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], t0 = kt[6], t1 = kt[7];
     const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
-    const int m = blockIdx.x * kBlock + tid;   // N is a multiple of the tile: every slot is live
+    const int m = tileb * kBlock + tid;   // N is a multiple of the tile: every slot is live
     const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
     float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
     // ---- round 0: everything addressable now
     const float w_max = d.scal[1];
     const float inv_n = 1.0f / (float)N;   // N is a power of two: x / N == x * inv_n exactly
-    const TreeEntry te = tree_entry_loads(d, i_ref);
+    TreeEntry te{};
+    if (half == 0) te = tree_entry_loads(d, i_ref);
     float uref[DMAX];
 #pragma unroll
     for (int r = 0; r < DMAX; ++r) uref[r] = r < d.du ? up[(size_t)r * N + i_ref] : 0.0f;
@@ -1073,7 +1082,24 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1t(LgDev dd, int s) {
     for (int r = 0; r < DMAX; ++r) xi[r] = r < d.du ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r) : 0.0f;
     FBSMI_STAMP(7)
     float last;
-    const int J = tree_build(d, te, L, i_ref, u3, w_max, inv_n, last);
+    int J;
+    if (HALVES == 1) {
+        J = tree_build(d, te, L, i_ref, u3, w_max, inv_n, last);
+    } else {
+        if (half == 0) {
+            J = tree_build(d, te, L, i_ref, u3, w_max, inv_n, last);
+            if (tid == 0) {
+                Jsh = J;
+                lastsh = last;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kTreeBuildBarriers; ++k) __syncthreads();   // the barriers of tree_build
+        }
+        __syncthreads();
+        J = Jsh;
+        last = lastsh;
+    }
     int shift = (j_ref - J) % N;   // roll by j - J (:85)
     if (shift < 0) shift += N;
     int src = m - shift;
@@ -1129,10 +1155,21 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1t(LgDev dd, int s) {
     lv[0] = l;
     FBSMI_STAMP(12)
     float mx, sx;
-    block_lse_partial<1>(lv, L.xch[0], L.xch[1], mx, sx);
+    {   // the tile's (max, sumexp): block_lse_partial per half
+        const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3, h4 = half * 4;
+        const float mw = wave_max(lv[0]);
+        if (lane == 0) part[0][h4 + wv] = mw;
+        __syncthreads();
+        mx = fmaxf(fmaxf(part[0][h4], part[0][h4 + 1]), fmaxf(part[0][h4 + 2], part[0][h4 + 3]));
+        TreePath pth;
+        const float sw_ = wave_upsweep(fbsmi_expf(lv[0] - finite_or_zero_f(mx)), pth);
+        if (lane == 0) part[1][h4 + wv] = sw_;
+        __syncthreads();
+        sx = (part[1][h4] + part[1][h4 + 1]) + (part[1][h4 + 2] + part[1][h4 + 3]);
+    }
     if (tid == 0) {
-        d.bmax[blockIdx.x] = mx;
-        d.bsumexp[blockIdx.x] = sx;
+        d.bmax[tileb] = mx;
+        d.bsumexp[tileb] = sx;
     }
     FBSMI_STAMP(13)
 }
@@ -2604,6 +2641,7 @@ struct fbsmi_lg_sweep {
     bool step_launches = false;  // FBSMI_STEP_LAUNCHES=1: one launch per step also where one launch per sweep is possible
     bool generic_prop = false;  // FBSMI_GENERIC_PROP=1: k_lg_prop also for one slot per thread (timing experiments)
     bool tree_step = true;  // FBSMI_TREE_STEP=0: keep the cdf launch also where the two-launch step applies
+    int tree_halves = -1;   // FBSMI_TREE_HALVES=1|2: tiles per workgroup of k_lg_prop1t (unset: two once there are two tiles per CU)
     int debug_mask = 7;  // FBSMI_DEBUG_STEP_MASK: bit0 norm, bit1 cdf, bit2 prop (timing experiments only)
     std::vector<hipEvent_t> prof_ev[kNumProfKernels];  // pairs (start, stop)
     double prof_us[kNumProfKernels] = {0, 0, 0};
@@ -2756,8 +2794,12 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                 k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
             } else if (tree && two_slot) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2t<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
+            } else if (tree && (s->tree_halves == 2 || (s->tree_halves < 0 && (int64_t)nb * d.C >= 2 * 256))) {
+                // two adjacent tiles per 512-thread workgroup: half the waves skip the tree building (measured +2 % at 4 chains,
+                // -1 % for a single chain, which keeps one tile per workgroup)
+                LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1t<DMAX, 2><<<dim3(nb / 2, d.C), 2 * kBlock, 0, st>>>(d, k)));
             } else if (tree) {
-                LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1t<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
+                LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1t<DMAX, 1><<<gtile, kBlock, 0, st>>>(d, k)));
             } else if (two_slot) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
             } else if (s->items == 1 && !s->generic_prop) {
@@ -2883,6 +2925,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     if (const char* sl = getenv("FBSMI_STEP_LAUNCHES")) s->step_launches = atoi(sl) != 0;
     if (const char* sp = getenv("FBSMI_TWO_SLOT_PROP")) s->two_slot_prop = atoi(sp) != 0 ? 1 : 0;
     if (const char* tp = getenv("FBSMI_TREE_STEP")) s->tree_step = atoi(tp) != 0;
+    if (const char* th = getenv("FBSMI_TREE_HALVES")) s->tree_halves = atoi(th) == 1 ? 1 : 2;
     s->items = fbsmi_tile_items(d.N);  // one workgroup = one tile of the two-level logsumexp (include/fbsmi_math.h)
     const int maxd = m->du > m->dv ? m->du : m->dv;
     s->dmax = maxd <= 1 ? 1 : (maxd <= 2 ? 2 : (maxd <= 4 ? 4 : 16));   // du = dv = 1 (BASELINE configs 1, 2) has its own instantiation
