@@ -1119,10 +1119,33 @@ __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) 
     const bool killed[1] = {u1 * w_max >= ws};                              // :71
     FBSMI_STAMP(10)
     // ---- rounds 3, 4 (killed slots only)
+    // The ancestor is one of the last four leaves or the slot behind them: for narrow states its row is fetched together
+    // with those leaves (one dependent round trip less).
+    constexpr bool kEarlyRow = DMAX <= 2;
+    float ucand[DMAX];
     if (killed[0]) {
         const TreeRound rd = tree_round_load(d, tile[0], h[0]);
         const int lo = tree_round_walk(rd, tile[0], h[0], qK[0], P[0], E[0]);
-        hi[0] = tree_leaves_walk(*reinterpret_cast<const float4*>(d.w + lo), lo, qK[0], P[0], E[0]);
+        const float4 w4 = *reinterpret_cast<const float4*>(d.w + lo);
+        float4 ug[DMAX];
+        float ue[DMAX];
+        if (kEarlyRow) {
+            const int e = lo + 4 < N ? lo + 4 : N - 1;
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) {
+                ug[r] = r < d.du ? *reinterpret_cast<const float4*>(up + (size_t)r * N + lo) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ue[r] = r < d.du ? up[(size_t)r * N + e] : 0.0f;
+            }
+        }
+        hi[0] = tree_leaves_walk(w4, lo, qK[0], P[0], E[0]);
+        if (kEarlyRow) {
+            const int k = hi[0] - lo;
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) {
+                const float lo2 = (k & 1) ? ug[r].y : ug[r].x, hi2 = (k & 1) ? ug[r].w : ug[r].z;
+                ucand[r] = k >= 4 ? ue[r] : ((k & 2) ? hi2 : lo2);
+            }
+        }
     }
     const bool pinned = m == j_ref;
     const int a = pinned ? i_ref : (killed[0] ? hi[0] : src);               // :86
@@ -1131,7 +1154,7 @@ __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) 
     if (killed[0] && !pinned) {
 #pragma unroll
         for (int r = 0; r < DMAX; ++r)
-            if (r < d.du) u[r] = up[(size_t)r * N + a];
+            if (r < d.du) u[r] = kEarlyRow ? ucand[r] : up[(size_t)r * N + a];
     }
     if (pinned) {
 #pragma unroll
