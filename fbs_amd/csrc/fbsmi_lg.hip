@@ -90,7 +90,7 @@ struct LgDev {
     int lh_w, lh_j;                         // their depths
     // two-launch step (N a power of two, 2..256 tiles): the searches walk the summation tree itself, so no cdf is written
     float2* trW;                            // [nb][64]: per tile, heap-ordered nodes (sum of the node's left half, w at its midpoint)
-    float2* trWtop;                         // [nb][8]: the first three levels of every tile's heap, compact (LDS staging)
+    float2* trWtop;                         // [nb][kMidN]: the first kMidLv levels of every tile's heap, compact (LDS staging)
     float* wfirst;                          // [nb]: w of every tile's first element
     float* scal;       // [16]: 0 lse, 1 w_max
     int32_t* As;       // [T][N] or null
@@ -129,6 +129,7 @@ struct LgDev {
 // depths of the compact heaps the cdf kernel publishes for k_lg_prop1
 constexpr int kHeapLevelsW = 11, kHeapSizeW = 1 << kHeapLevelsW;
 constexpr int kHeapLevelsJ = 8, kHeapSizeJ = 1 << kHeapLevelsJ;
+constexpr int kMidLv = 3, kMidN = 1 << kMidLv;   // levels (nodes) of every tile's tree the Euler kernel keeps in LDS (4 measured: staging 32 KB per workgroup costs more than the two probes it saves)
 constexpr int kTreeNodes = 64;   // nodes of a tile's summation tree that are published (down to blocks of 8 leaves)
 
 __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
@@ -164,7 +165,7 @@ __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
     }
     if (d.trW) {
         d.trW += kTreeNodes * nb * c;
-        d.trWtop += 8 * nb * c;
+        d.trWtop += kMidN * nb * c;
         d.wfirst += nb * c;
     }
     d.scal += 16 * (size_t)c;
@@ -510,7 +511,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
             const int h = i ? tree_mid_node(i) : 0;
             const float2 node = make_float2(i ? tree_left_sum(p2[0], i) : 0.0f, xw[0]);
             d.trW[(size_t)blockIdx.x * kTreeNodes + h] = node;
-            if (h < 8) d.trWtop[blockIdx.x * 8 + h] = node;
+            if (h < kMidN) d.trWtop[blockIdx.x * kMidN + h] = node;
             if (i == 0) d.wfirst[blockIdx.x] = node.y;
         }
     }
@@ -911,7 +912,7 @@ __device__ __forceinline__ bool tree_walk(float2 nd, float q, float& P, float& E
 // what a workgroup of the two-launch step loads at entry for the trees (issued before the noise draws)
 struct TreeEntry {
     float sw, sj, wf, wr;   // tile `tid`: sum of w, sum of J_prob ([i*] = 0), w of its first element; w of the tile of i*
-    float4 stg[4];          // this thread's part of trWtop
+    float4 stg[kMidN / 2];  // this thread's part of trWtop
 };
 
 __device__ __forceinline__ TreeEntry tree_entry_loads(const LgDev& d, int i_ref) {
@@ -923,9 +924,9 @@ __device__ __forceinline__ TreeEntry tree_entry_loads(const LgDev& d, int i_ref)
     e.wf = tl ? d.wfirst[tid] : 0.0f;
     e.wr = d.w[(i_ref / kBlock) * kBlock + tid];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kMidN / 2; ++k) {
         const int idx = tid + kBlock * k;
-        e.stg[k] = idx < 4 * nb ? reinterpret_cast<const float4*>(d.trWtop)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        e.stg[k] = idx < kMidN / 2 * nb ? reinterpret_cast<const float4*>(d.trWtop)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return e;
 }
@@ -935,7 +936,7 @@ __device__ __forceinline__ TreeEntry tree_entry_loads(const LgDev& d, int i_ref)
 struct TreeLds {
     float xch[5][4];
     float2 topW[kBlock], topJ[kBlock], tileJ[kBlock];
-    __attribute__((aligned(16))) float2 midW[8 * kBlock];
+    __attribute__((aligned(16))) float2 midW[kMidN * kBlock];
 };
 
 constexpr int kTreeBuildBarriers = 6;   // __syncthreads() executed by tree_build (four up-sweep exchanges, two explicit)
@@ -947,9 +948,9 @@ __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, Tr
     const int nb = d.nb, tid = threadIdx.x;
     const int b_ref = i_ref / kBlock;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kMidN / 2; ++k) {
         const int idx = tid + kBlock * k;
-        if (idx < 4 * nb) reinterpret_cast<float4*>(L.midW)[idx] = e.stg[k];
+        if (idx < kMidN / 2 * nb) reinterpret_cast<float4*>(L.midW)[idx] = e.stg[k];
     }
     // ---- the levels above the tiles: sums of w, sums of J_prob with [i*] = 0 (one exchange)
     const int g = tid ? tree_mid_node(tid) : 0;
@@ -1006,13 +1007,14 @@ __device__ __forceinline__ void tree_search_lds(const TreeLds& L, int nb, float 
     tile = h - kBlock;
     h = 1;
 #pragma unroll
-    for (int l = 0; l < 3; ++l) h = 2 * h + (tree_walk(L.midW[tile * 8 + h], q, P, E) ? 0 : 1);
+    for (int l = 0; l < kMidLv; ++l) h = 2 * h + (tree_walk(L.midW[tile * kMidN + h], q, P, E) ? 0 : 1);
 }
 
 // ... the rest: nodes of 32, 16, 8 leaves from the tile's published heap in one round trip, the last four leaves of
 // w in another.  K searches in lockstep (all loads of a round issued before the first is used); `on` = false: no
 // loads, result untouched.
-struct TreeRound {   // the seven nodes of one three-level round, as scalars (selects between vector loads end up in scratch)
+struct TreeRound {   // the nodes between the LDS levels and the last four leaves, as scalars (selects between vector
+                     // loads end up in scratch): one node of 16 leaves and its children (kMidLv = 4), or three levels
     float s1, y1, s2l, y2l, s2r, y2r, s3a, y3a, s3b, y3b, s3c, y3c, s3d, y3d;
 };
 
@@ -1020,20 +1022,27 @@ __device__ __forceinline__ TreeRound tree_round_load(const LgDev& d, int tile, i
     const float2* tr = d.trW + (size_t)tile * kTreeNodes;
     const float2 n1 = tr[h];
     const float4 n2 = *reinterpret_cast<const float4*>(tr + 2 * h);
-    const float4 n3a = *reinterpret_cast<const float4*>(tr + 4 * h);
-    const float4 n3b = *reinterpret_cast<const float4*>(tr + 4 * h + 2);
-    return TreeRound{n1.x, n1.y, n2.x, n2.y, n2.z, n2.w, n3a.x, n3a.y, n3a.z, n3a.w, n3b.x, n3b.y, n3b.z, n3b.w};
+    if constexpr (kMidLv == 4) {
+        return TreeRound{n1.x, n1.y, n2.x, n2.y, n2.z, n2.w, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    } else {
+        const float4 n3a = *reinterpret_cast<const float4*>(tr + 4 * h);
+        const float4 n3b = *reinterpret_cast<const float4*>(tr + 4 * h + 2);
+        return TreeRound{n1.x, n1.y, n2.x, n2.y, n2.z, n2.w, n3a.x, n3a.y, n3a.z, n3a.w, n3b.x, n3b.y, n3b.z, n3b.w};
+    }
 }
 
-// three levels; returns the first of the four leaves the walk arrived at
+// walks those levels; returns the first of the four leaves the walk arrived at
 __device__ __forceinline__ int tree_round_walk(const TreeRound r, int tile, int h, float q, float& P, float& E) {
+    static_assert(kMidLv == 3 || kMidLv == 4, "the round covers the levels between the LDS part and the last four leaves");
     const bool g1 = tree_walk(make_float2(r.s1, r.y1), q, P, E);
     const bool g2 = tree_walk(make_float2(g1 ? r.s2l : r.s2r, g1 ? r.y2l : r.y2r), q, P, E);
-    const float s3 = g1 ? (g2 ? r.s3a : r.s3b) : (g2 ? r.s3c : r.s3d);
-    const float y3 = g1 ? (g2 ? r.y3a : r.y3b) : (g2 ? r.y3c : r.y3d);
-    const bool g3 = tree_walk(make_float2(s3, y3), q, P, E);
-    const int h4 = 8 * h + (g1 ? 0 : 4) + (g2 ? 0 : 2) + (g3 ? 0 : 1);   // a node of four leaves: 64 <= h4 < 128
-    return tile * kBlock + (h4 - 64) * 4;
+    int h4 = 4 * h + (g1 ? 0 : 2) + (g2 ? 0 : 1);
+    if constexpr (kMidLv == 3) {
+        const float s3 = g1 ? (g2 ? r.s3a : r.s3b) : (g2 ? r.s3c : r.s3d);
+        const float y3 = g1 ? (g2 ? r.y3a : r.y3b) : (g2 ? r.y3c : r.y3d);
+        h4 = 2 * h4 + (tree_walk(make_float2(s3, y3), q, P, E) ? 0 : 1);
+    }
+    return tile * kBlock + (h4 - 64) * 4;   // a node of four leaves: 64 <= h4 < 128
 }
 
 // the last four leaves (w4 = w[lo .. lo + 3]) and the closing one-leaf level
@@ -1046,13 +1055,13 @@ __device__ __forceinline__ int tree_leaves_walk(float4 w4, int lo, float q, floa
     return q <= e1 ? leaf : leaf + 1;
 }
 
-// HALVES = 2: a workgroup of 512 threads owns two adjacent tiles; its first half builds the trees and finds J (the
-// other four waves wait at the barriers instead of repeating ~450 instructions each), then every thread does its slot.
+// HALVES = 2, 4: a workgroup of 512 / 1024 threads owns adjacent tiles; its first 256 threads build the trees and find J
+// (the other waves wait at the barriers instead of repeating ~450 instructions each), then every thread does its slot.
 template <int DMAX, int HALVES>
 __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) {
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ TreeLds L;
-    __shared__ float part[2][8];
+    __shared__ float part[2][4 * HALVES];
     __shared__ int Jsh;
     __shared__ float lastsh;
     FBSMI_STAMP(6)
@@ -1274,8 +1283,8 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop2t(LgDev dd, int s) {
         tile[1] = h1 - kBlock;
         h0 = h1 = 1;
 #pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            const float2 n0 = L.midW[tile[0] * 8 + h0], n1 = L.midW[tile[1] * 8 + h1];
+        for (int l = 0; l < kMidLv; ++l) {
+            const float2 n0 = L.midW[tile[0] * kMidN + h0], n1 = L.midW[tile[1] * kMidN + h1];
             h0 = 2 * h0 + (tree_walk(n0, qK[0], P[0], E[0]) ? 0 : 1);
             h1 = 2 * h1 + (tree_walk(n1, qK[1], P[1], E[1]) ? 0 : 1);
         }
@@ -2664,7 +2673,7 @@ struct fbsmi_lg_sweep {
     bool step_launches = false;  // FBSMI_STEP_LAUNCHES=1: one launch per step also where one launch per sweep is possible
     bool generic_prop = false;  // FBSMI_GENERIC_PROP=1: k_lg_prop also for one slot per thread (timing experiments)
     bool tree_step = true;  // FBSMI_TREE_STEP=0: keep the cdf launch also where the two-launch step applies
-    int tree_halves = -1;   // FBSMI_TREE_HALVES=1|2: tiles per workgroup of k_lg_prop1t (unset: two once there are two tiles per CU)
+    int tree_halves = -1;   // FBSMI_TREE_HALVES=1|2|4: tiles per workgroup of k_lg_prop1t (unset: as many as there are tiles per CU, up to 4)
     int debug_mask = 7;  // FBSMI_DEBUG_STEP_MASK: bit0 norm, bit1 cdf, bit2 prop (timing experiments only)
     std::vector<hipEvent_t> prof_ev[kNumProfKernels];  // pairs (start, stop)
     double prof_us[kNumProfKernels] = {0, 0, 0};
@@ -2817,6 +2826,10 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                 k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
             } else if (tree && two_slot) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2t<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
+            } else if (tree && nb % 4 == 0 && (s->tree_halves == 4 || (s->tree_halves < 0 && (int64_t)nb * d.C >= 4 * 256))) {
+                // four tiles per 1024-thread workgroup once there are four tiles per CU (measured 8.57 against 8.80 ms per
+                // 4-chain sweep with two; a single chain is fastest with one tile per workgroup)
+                LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1t<DMAX, 4><<<dim3(nb / 4, d.C), 4 * kBlock, 0, st>>>(d, k)));
             } else if (tree && (s->tree_halves == 2 || (s->tree_halves < 0 && (int64_t)nb * d.C >= 2 * 256))) {
                 // two adjacent tiles per 512-thread workgroup: half the waves skip the tree building (measured +2 % at 4 chains,
                 // -1 % for a single chain, which keeps one tile per workgroup)
@@ -2948,7 +2961,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     if (const char* sl = getenv("FBSMI_STEP_LAUNCHES")) s->step_launches = atoi(sl) != 0;
     if (const char* sp = getenv("FBSMI_TWO_SLOT_PROP")) s->two_slot_prop = atoi(sp) != 0 ? 1 : 0;
     if (const char* tp = getenv("FBSMI_TREE_STEP")) s->tree_step = atoi(tp) != 0;
-    if (const char* th = getenv("FBSMI_TREE_HALVES")) s->tree_halves = atoi(th) == 1 ? 1 : 2;
+    if (const char* th = getenv("FBSMI_TREE_HALVES")) s->tree_halves = atoi(th) == 1 ? 1 : (atoi(th) == 4 ? 4 : 2);
     s->items = fbsmi_tile_items(d.N);  // one workgroup = one tile of the two-level logsumexp (include/fbsmi_math.h)
     const int maxd = m->du > m->dv ? m->du : m->dv;
     s->dmax = maxd <= 1 ? 1 : (maxd <= 2 ? 2 : (maxd <= 4 ? 4 : 16));   // du = dv = 1 (BASELINE configs 1, 2) has its own instantiation
@@ -3012,7 +3025,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     d.wfirst = nullptr;
     if (s->items == 1 && !wide && (d.N & (d.N - 1)) == 0 && d.nb >= 2 && d.nb <= kBlock) {
         rc |= slab_request(s, &d.trW, C * (size_t)kTreeNodes * d.nb);
-        rc |= slab_request(s, &d.trWtop, C * 8 * (size_t)d.nb);
+        rc |= slab_request(s, &d.trWtop, C * (size_t)kMidN * d.nb);
         rc |= slab_request(s, &d.wfirst, C * (size_t)d.nb);
     }
     rc |= slab_request(s, &d.bsumw, C * d.nb);

@@ -385,13 +385,15 @@ def test_toy_filter_and_pmcmc_drivers(tmp_path, dev):
     assert set(np.load(os.path.join(str(tmp_path), "pmcmc-0.005-const-200-666.npz")).files) == {"samples", "gp_mean", "gp_cov"}
 
 
-@pytest.mark.parametrize("tree", ["1", "0", "one-tile-workgroups"])
+@pytest.mark.parametrize("tree", ["1", "0", "one-tile-workgroups", "four-tile-workgroups"])
 def test_tree_step_reference_indices_on_tile_edges(tree, oracle, dev, monkeypatch):
     """The two-launch step (searches walk the summation tree) and the three-launch step it replaces (FBSMI_TREE_STEP=0)
     with the reference path sitting on tile boundaries: first / last element of a tile, of the ensemble."""
     monkeypatch.setenv("FBSMI_TREE_STEP", "0" if tree == "0" else "1")
     if tree == "one-tile-workgroups":   # k_lg_prop1t<., 1> instead of the 512-thread workgroups that own two tiles
         monkeypatch.setenv("FBSMI_TREE_HALVES", "1")
+    if tree == "four-tile-workgroups":
+        monkeypatch.setenv("FBSMI_TREE_HALVES", "4")
     toy = toy_2d()
     N, T = 1024, 12
     ts = np.linspace(0, 1.0, T + 1)
