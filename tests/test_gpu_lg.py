@@ -413,6 +413,32 @@ def test_tree_step_reference_indices_on_tile_edges(tree, oracle, dev, monkeypatc
             _eq(_np(got[i]), want[i], what)
 
 
+@pytest.mark.parametrize("tiles,toy,N,T,C", [("2", toy_4d, 4096, 6, 2), ("4", toy_31, 8192, 5, 3), ("", toy_2d, 65536, 3, 4)])
+def test_tree_step_workgroups_owning_several_tiles(tiles, toy, N, T, C, oracle, dev, monkeypatch):
+    """k_lg_prop1t<., 2 | 4>: 512 / 1024-thread workgroups own adjacent tiles and only the first 256 threads build the trees
+    and find J.  Forced on mid-sized ensembles (several workgroups per chain), and by its own rule at BASELINE config 2's
+    size with the reference's four chains."""
+    if tiles:
+        monkeypatch.setenv("FBSMI_TREE_HALVES", tiles)
+    toy_ = toy()
+    ts = np.linspace(0, 1.0, T + 1)
+    br = _bridge(toy_, ts, dev)
+    om = oracle_model_from(oracle, br)
+    rng = np.random.default_rng(N + C)
+    x0 = rng.normal(size=(C, br.du)).astype(np.float32)
+    bs = rng.integers(0, N, (C, T + 1)).astype(np.int32)
+    keys = oracle.split(oracle.PRNGKey(23), C)
+    sweep = br.sweep_handle(N, True, False, nchains=C)
+    got = sweep.sweep(keys, x0, toy_["y0"], bs)
+    v = sweep.views()
+    for c in range(C):
+        want = oracle.gibbs_kernel_lg(om, keys[c], x0[c], toy_["y0"], bs[c], N, True, False, debug=True)
+        for i, what in enumerate(("x0_next", "us_star_next", "bs_star_next", "acc")):
+            _eq(_np(got[i][c]), want[i], f"{what} chain {c}")
+        _eq(_np(v["us_T"][c]), want[4], f"particles chain {c}")
+        _eq(_np(v["lw_T"][c]), want[5], f"log-weights chain {c}")
+
+
 @pytest.mark.parametrize("tree", ["1", "0"])
 def test_two_slot_prop_kernel_matches_oracle(tree, oracle, dev, monkeypatch):
     """k_lg_prop2 / k_lg_prop2t (two slots per thread, N/2 apart: the kill-test / redraw / noise draws of both slots
