@@ -909,6 +909,23 @@ __device__ __forceinline__ bool tree_walk(float2 nd, float q, float& P, float& E
     return gl;
 }
 
+// Two levels of a heap-ordered tree in ONE LDS round trip: the node and both children (adjacent: one 16-byte read) are
+// fetched together.  Returns the heap index two levels down.
+__device__ __forceinline__ int tree_walk2(const float2* heap, int h, float q, float& P, float& E) {
+    const float2 a = heap[h];
+    const float4 c = *reinterpret_cast<const float4*>(heap + 2 * h);
+    const bool g1 = tree_walk(a, q, P, E);
+    const bool g2 = tree_walk(g1 ? make_float2(c.x, c.y) : make_float2(c.z, c.w), q, P, E);
+    return 4 * h + (g1 ? 0 : 2) + (g2 ? 0 : 1);
+}
+
+// `levels` levels from node h
+__device__ __forceinline__ int tree_walk_n(const float2* heap, int h, int levels, float q, float& P, float& E) {
+    for (; levels >= 2; levels -= 2) h = tree_walk2(heap, h, q, P, E);
+    if (levels) h = 2 * h + (tree_walk(heap[h], q, P, E) ? 0 : 1);
+    return h;
+}
+
 // what a workgroup of the two-launch step loads at entry for the trees (issued before the noise draws)
 struct TreeEntry {
     float sw, sj, wf, wr;   // tile `tid`: sum of w, sum of J_prob ([i*] = 0), w of its first element; w of the tile of i*
@@ -935,7 +952,7 @@ __device__ __forceinline__ TreeEntry tree_entry_loads(const LgDev& d, int i_ref)
 // first three levels of every tile's w heap
 struct TreeLds {
     float xch[5][4];
-    float2 topW[kBlock], topJ[kBlock], tileJ[kBlock];
+    __attribute__((aligned(16))) float2 topW[kBlock], topJ[kBlock], tileJ[kBlock];
     __attribute__((aligned(16))) float2 midW[kMidN * kBlock];
 };
 
@@ -977,9 +994,9 @@ __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, Tr
     // ---- the walk for J.  The interval of the bisection is the node itself ([lo, hi) = the node's leaves), so the
     // walk only keeps the heap index.
     const float q = lastJ * (1.0f - u3);
-    int h = kBlock / nb;
+    const int top_levels = 31 - __builtin_clz(nb);
     float P = 0.0f, E = lastJ;
-    for (int l = nb; l > 1; l >>= 1) h = 2 * h + (tree_walk(L.topJ[h], q, P, E) ? 0 : 1);
+    int h = tree_walk_n(L.topJ, kBlock / nb, top_levels, q, P, E);
     const int lo0 = (h - kBlock) * kBlock;   // first slot of the tile the walk arrived at
     const float wj = d.w[lo0 + tid];
     s1[0] = lo0 + tid == i_ref ? Ji : jprob_pow2(wj, w_max, inv_n);
@@ -987,14 +1004,15 @@ __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, Tr
     block_upsweep_n<1>(s1, p1, L.xch[4], t1s);
     if (tid) L.tileJ[g] = make_float2(tree_left_sum(p1[0], tid), xj);
     __syncthreads();
-    h = 1;
-#pragma unroll
-    for (int l = 0; l < 7; ++l) h = 2 * h + (tree_walk(L.tileJ[h], q, P, E) ? 0 : 1);
-    {   // two leaves: the probe is E itself
-        const float tt = P + L.tileJ[h].x;
+    h = tree_walk_n(L.tileJ, 1, 6, q, P, E);
+    {   // the node of four leaves and, in the same round trip, its children: two leaves, whose probe is E itself
+        const float2 a = L.tileJ[h];
+        const float4 c = *reinterpret_cast<const float4*>(L.tileJ + 2 * h);
+        const bool g1 = tree_walk(a, q, P, E);
+        const float tt = P + (g1 ? c.x : c.z);
         const bool gl = q <= E;
         E = gl ? tt : E;
-        h = 2 * h + (gl ? 0 : 1);
+        h = 4 * h + (g1 ? 0 : 2) + (gl ? 0 : 1);
     }
     const int leaf = lo0 + h - kBlock;
     return q <= E ? leaf : leaf + 1;
@@ -1002,12 +1020,9 @@ __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, Tr
 
 // Cat(w) search, LDS part: down to a node of 32 leaves (heap index h of tile `tile`)
 __device__ __forceinline__ void tree_search_lds(const TreeLds& L, int nb, float q, float& P, float& E, int& tile, int& h) {
-    h = kBlock / nb;
-    for (int l = nb; l > 1; l >>= 1) h = 2 * h + (tree_walk(L.topW[h], q, P, E) ? 0 : 1);
+    h = tree_walk_n(L.topW, kBlock / nb, 31 - __builtin_clz(nb), q, P, E);
     tile = h - kBlock;
-    h = 1;
-#pragma unroll
-    for (int l = 0; l < kMidLv; ++l) h = 2 * h + (tree_walk(L.midW[tile * kMidN + h], q, P, E) ? 0 : 1);
+    h = tree_walk_n(L.midW + tile * kMidN, 1, kMidLv, q, P, E);
 }
 
 // ... the rest: nodes of 32, 16, 8 leaves from the tile's published heap in one round trip, the last four leaves of
