@@ -1286,23 +1286,33 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop2t(LgDev dd, int s) {
     const float qK[2] = {last * (1.0f - u2[0]), last * (1.0f - u2[1])};    // resamplings.py:73-74
     float P[2] = {0.0f, 0.0f}, E[2] = {last, last};
     int tile[2], h[2], hi[2] = {0, 0};
-    {   // the two LDS walks in lockstep
-        const int nb = d.nb;
-        int h0 = kBlock / nb, h1 = h0;
-        for (int l = nb; l > 1; l >>= 1) {
-            const float2 n0 = L.topW[h0], n1 = L.topW[h1];
+    {   // the two LDS walks in lockstep (all reads of a round trip issued before the first is used), two levels per trip
+        auto walk2x2 = [&](const float2* hp0, const float2* hp1, int& h0, int& h1) {
+            const float2 a0 = hp0[h0], a1 = hp1[h1];
+            const float4 c0 = *reinterpret_cast<const float4*>(hp0 + 2 * h0), c1 = *reinterpret_cast<const float4*>(hp1 + 2 * h1);
+            const bool g0 = tree_walk(a0, qK[0], P[0], E[0]), g1 = tree_walk(a1, qK[1], P[1], E[1]);
+            const bool k0 = tree_walk(g0 ? make_float2(c0.x, c0.y) : make_float2(c0.z, c0.w), qK[0], P[0], E[0]);
+            const bool k1 = tree_walk(g1 ? make_float2(c1.x, c1.y) : make_float2(c1.z, c1.w), qK[1], P[1], E[1]);
+            h0 = 4 * h0 + (g0 ? 0 : 2) + (k0 ? 0 : 1);
+            h1 = 4 * h1 + (g1 ? 0 : 2) + (k1 ? 0 : 1);
+        };
+        auto walk1x2 = [&](const float2* hp0, const float2* hp1, int& h0, int& h1) {
+            const float2 n0 = hp0[h0], n1 = hp1[h1];
             h0 = 2 * h0 + (tree_walk(n0, qK[0], P[0], E[0]) ? 0 : 1);
             h1 = 2 * h1 + (tree_walk(n1, qK[1], P[1], E[1]) ? 0 : 1);
-        }
+        };
+        const int nb = d.nb;
+        int h0 = kBlock / nb, h1 = h0, lv = 31 - __builtin_clz(nb);
+        for (; lv >= 2; lv -= 2) walk2x2(L.topW, L.topW, h0, h1);
+        if (lv) walk1x2(L.topW, L.topW, h0, h1);
         tile[0] = h0 - kBlock;
         tile[1] = h1 - kBlock;
+        const float2 *m0 = L.midW + tile[0] * kMidN, *m1 = L.midW + tile[1] * kMidN;
         h0 = h1 = 1;
-#pragma unroll
-        for (int l = 0; l < kMidLv; ++l) {
-            const float2 n0 = L.midW[tile[0] * kMidN + h0], n1 = L.midW[tile[1] * kMidN + h1];
-            h0 = 2 * h0 + (tree_walk(n0, qK[0], P[0], E[0]) ? 0 : 1);
-            h1 = 2 * h1 + (tree_walk(n1, qK[1], P[1], E[1]) ? 0 : 1);
-        }
+        static_assert(kMidLv == 3 || kMidLv == 4, "walk of the tile levels kept in LDS");
+        walk2x2(m0, m1, h0, h1);
+        if (kMidLv == 4) walk2x2(m0, m1, h0, h1);
+        else walk1x2(m0, m1, h0, h1);
         h[0] = h0;
         h[1] = h1;
     }
