@@ -11,7 +11,7 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SRC = [os.path.join(_HERE, "csrc", n) for n in ("fbsmi_prims.hip", "fbsmi_lg.hip", "fbsmi_sde.hip", "fbsmi_nn.hip")]
+_SRC = [os.path.join(_HERE, "csrc", n) for n in ("fbsmi_prims.hip", "fbsmi_lg.hip", "fbsmi_sde.hip", "fbsmi_nn.hip", "fbsmi_em.hip")]
 _DEPS = _SRC + [os.path.join(_HERE, "csrc", "fbsmi_device.h"), os.path.join(_HERE, "csrc", "fbsmi_host.h"),
                 os.path.join(_HERE, "..", "include", "fbsmi.h"), os.path.join(_HERE, "..", "include", "fbsmi_math.h"),
                 os.path.join(_HERE, "..", "include", "fbsmi_nn.h")]
@@ -49,6 +49,11 @@ class LGModelStruct(C.Structure):
     _fields_ = [("du", C.c_int32), ("dv", C.c_int32), ("T", C.c_int32), ("dt", C.c_float),
                 ("G", C.c_void_p), ("g", C.c_void_p), ("sd", C.c_void_p), ("lognorm", C.c_void_p),
                 ("F", C.c_void_p), ("sqQ", C.c_void_p)]
+
+
+class EMMaskStruct(C.Structure):
+    _fields_ = [("du", C.c_int32), ("dv", C.c_int32), ("u_off", C.c_void_p), ("v_off", C.c_void_p),
+                ("role", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every int-returning entry is status-checked by call()
@@ -92,6 +97,11 @@ SIGNATURES = {
     "fbsmi_lg_filter_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "fbsmi_lg_sweep_profile": (C.c_int, [_vp, C.c_int]),
     "fbsmi_lg_sweep_kernel_us": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "fbsmi_em_concat": (C.c_int, [C.POINTER(EMMaskStruct), _vp, _vp, _vp, _i64, C.c_int, _vp, _vp]),
+    "fbsmi_em_finish": (C.c_int, [C.POINTER(EMMaskStruct), _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f, _f, _f, _f, _vp, _vp,
+                                  _u32, _u32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "fbsmi_em_transition_logpdf": (C.c_int, [C.POINTER(EMMaskStruct), _vp, _vp, C.c_int, C.c_int, _f, _f, _f, _f, _vp,
+                                             _i64, _vp, _vp]),
     # include/fbsmi_nn.h
     "fbsmi_nn_linear_attention": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp]),
     "fbsmi_nn_channel_layernorm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _vp, _f, _vp, _vp]),
@@ -105,7 +115,8 @@ def lib() -> C.CDLL:
     """Load libfbsmi.so (building it first when the sources are newer)."""
     global _lib
     if _lib is None:
-        path = build()
+        # FBSMI_LIB: a diagnostic build of the same sources (tools/build_variants.sh) instead of the in-tree library
+        path = os.environ.get("FBSMI_LIB") or build()
         try:
             L = C.CDLL(path)
         except OSError as e:  # no silent fallback

@@ -1,0 +1,475 @@
+// fbsmi_em.hip -- the SMC step of score-network models (BASELINE configs 3-5) around ONE network
+// evaluation per step: what experiments/imgs/inpainting.py:102-147 (and supr.py, sb_imgs/supr.py:80-127)
+// spread over concat / unpack / drift / Euler-Maruyama / norm.logpdf / jnp.sum, as two kernels.
+//
+//   k_em_concat : img[r] = concat(us[A[r]], v_prev)            (csmc.py:140, fbs/data/images.py:355-363)
+//   k_em_finish : unpack(net) -> reverse drift -> proposal with in-kernel jax.random.normal -> pin
+//                 -> row-summed Gaussian log-density             (inpainting.py:102-147, csmc.py:143-145)
+//
+// This is the one place on the path where the per-particle state is kilobytes, so the bound is HBM
+// bandwidth: per particle the finish kernel reads the network output once (4 D bytes), the ancestor's
+// row once (4 du) and writes the new row once (4 du) and one log-weight.  Its workgroups have two roles,
+// interleaved over the grid so that both kinds are resident on every CU at the same time:
+//   * proposal groups walk the FLAT index space of the (rows, du) draw.  jax's random_bits puts elements
+//     i and i + n/2 of a draw on the two output words of one Threefry call, so a thread that owns
+//     elements i..i+3 also owns i+n/2..i+n/2+3: eight normals out of four block-cipher calls.  These
+//     groups are bound by vector-instruction issue (Threefry-2x32/20 + the erf_inv expansion, ~200
+//     instructions per normal);
+//   * log-density groups own one particle row: every wave reduces 256 consecutive observed elements at a
+//     time in the canonical pairwise order (4 in the lane, 6 butterfly levels), the segment sums meet in
+//     LDS.  These groups are bound by the memory system.
+// Reads of the network output go through the mask's offset tables (runs of s*c contiguous floats for an
+// s x s inpainting rectangle): 16-byte loads wherever a lane's four offsets are consecutive.
+// gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/fbsmi.h"
+#include "fbsmi_device.h"
+#include "fbsmi_host.h"
+
+namespace fbsmi {
+
+namespace {
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));           // 16-byte load, dword aligned
+typedef unsigned short us4u __attribute__((ext_vector_type(4), aligned(2)));  // four bf16, 2-byte aligned
+
+#ifndef FBSMI_EM_SEGBATCH
+#define FBSMI_EM_SEGBATCH 2
+#endif
+constexpr int kSegBatch = FBSMI_EM_SEGBATCH;  // 256-element segments a wave keeps in flight (log-density role)
+#ifndef FBSMI_EM_WAVES
+#define FBSMI_EM_WAVES 6  // waves per SIMD the finish kernel is compiled for (80 registers: no spills)
+#endif
+
+struct EmArgs {
+    const float* us;
+    const int32_t* A;
+    const int32_t* net_A;  // row of `net` that belongs to local row r (NULL: r)
+    const void* net;
+    const float* v;        // target of the log-density (observed part: v; transition_logpdf: u)
+    const float* v_prev;
+    const float* pin_value;
+    float* us_new;
+    float* lw;
+    const int32_t* u_off;
+    const int32_t* v_off;
+    int32_t du, dv, D;
+    float cx, cs, dt, sd;
+    uint32_t k0, k1;
+    uint32_t ntot_el;  // n_total * du: size of the flat draw
+    uint32_t half;     // (ntot_el + 1) / 2
+    uint32_t first_el; // row0 * du
+    uint32_t nloc_el;  // n * du
+    int32_t n;
+    int32_t pin_row;   // local row, -1: none
+    int32_t nU, nV;    // proposal / log-density workgroups
+};
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return fbsmi_u2f((uint32_t)h << 16); }
+
+// round to nearest even; NaN stays NaN
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    const uint32_t u = fbsmi_f2u(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <int NETDT>
+__device__ __forceinline__ float net_at(const void* net, int64_t idx) {
+    if (NETDT == 0) return ((const float*)net)[idx];
+    return bf16_to_f32(((const unsigned short*)net)[idx]);
+}
+
+// four network values at offsets o[0..3] of a row; `contig` (wave-uniform) = every lane's offsets are consecutive
+template <int NETDT>
+__device__ __forceinline__ void net_at4(const void* net, int64_t row_base, const int (&o)[4], bool contig, float (&s)[4]) {
+    if (contig) {
+        if (NETDT == 0) {
+            const f4u t = *(const f4u*)((const float*)net + row_base + o[0]);
+            s[0] = t.x; s[1] = t.y; s[2] = t.z; s[3] = t.w;
+        } else {
+            const us4u t = *(const us4u*)((const unsigned short*)net + row_base + o[0]);
+            s[0] = bf16_to_f32(t.x); s[1] = bf16_to_f32(t.y); s[2] = bf16_to_f32(t.z); s[3] = bf16_to_f32(t.w);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = net_at<NETDT>(net, row_base + o[k]);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ float em_drift(float cx, float cs, float x, float s) {
+    if (MODE == 1) return s;
+    const float t1 = cx * x, t2 = cs * s;
+    return t1 + t2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// proposal: four consecutive flat elements [e0, e0 + 4) of the global draw (those below `lim`), with
+// their four random words.  VEC: du % 4 == 0 and e0 % 4 == 0, so the four sit in one row, 16-byte
+// aligned.
+// ------------------------------------------------------------------------------------------------
+template <bool VEC, int NETDT, int MODE>
+__device__ __forceinline__ void em_u_group(const EmArgs& a, uint32_t e0, uint32_t lim, const uint32_t (&bits)[4]) {
+    const uint32_t le = e0 - a.first_el;
+    const uint32_t du = (uint32_t)a.du;
+    uint32_t r = le / du, p = le - r * du;
+    if (VEC) {
+        const int64_t src = a.A ? (int64_t)a.A[r] : (int64_t)r;
+        const float4 x4 = *(const float4*)(a.us + src * du + p);
+        const int4 o4 = *(const int4*)(a.u_off + p);
+        const int o[4] = {o4.x, o4.y, o4.z, o4.w};
+        const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+        float s[4], y[4];
+        const bool contig = __all(o[3] - o[0] == 3);
+        net_at4<NETDT>(a.net, (int64_t)(a.net_A ? a.net_A[r] : (int32_t)r) * a.D, o, contig, s);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float z = normal_from_bits(bits[k]);
+            const float d = em_drift<MODE>(a.cx, a.cs, x[k], s[k]);
+            const float m = x[k] + d * a.dt;
+            const float nz = a.sd * z;
+            y[k] = m + nz;
+        }
+        float4 out = make_float4(y[0], y[1], y[2], y[3]);
+        if ((int32_t)r == a.pin_row) {
+            const f4u pv = *(const f4u*)(a.pin_value + p);
+            out = make_float4(pv.x, pv.y, pv.z, pv.w);
+        }
+        *(float4*)(a.us_new + (int64_t)r * du + p) = out;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (e0 + k < lim) {
+                const int64_t src = a.A ? (int64_t)a.A[r] : (int64_t)r;
+                const float x = a.us[src * du + p];
+                const float s = net_at<NETDT>(a.net, (int64_t)(a.net_A ? a.net_A[r] : (int32_t)r) * a.D + a.u_off[p]);
+                const float z = normal_from_bits(bits[k]);
+                const float d = em_drift<MODE>(a.cx, a.cs, x, s);
+                const float m = x + d * a.dt;
+                const float nz = a.sd * z;
+                float y = m + nz;
+                if ((int32_t)r == a.pin_row) y = a.pin_value[p];
+                a.us_new[(int64_t)r * du + p] = y;
+            }
+            if (++p == du) { p = 0; ++r; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// log-density of one row: sum over the d elements of a part (PART 0: observed pixels, base v_prev[j]
+// shared by all rows; PART 1: unobserved pixels, base us[row][j]) of
+//     ( log(2 pi sd^2) + (target[j] - (base + drift * dt))^2 / sd^2 ) / -2
+// in the pairwise order of orc_sum (adjacent pairs, zero padded).  `seg` = LDS scratch of
+// max(64, segments) floats.  Every thread of the workgroup must call it; thread 0 returns the sum.
+// ------------------------------------------------------------------------------------------------
+template <int NETDT, int MODE, int PART>
+__device__ __forceinline__ float em_row_logpdf(const EmArgs& a, int32_t r, float* seg) {
+    const int d = PART == 0 ? a.dv : a.du;
+    const int32_t* __restrict__ offt = PART == 0 ? a.v_off : a.u_off;
+    const float* __restrict__ basep = PART == 0 ? a.v_prev : a.us + (int64_t)r * a.du;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg = (d + 255) >> 8;
+    const float var = a.sd * a.sd;
+    const float lognorm = fbsmi_logf(6.2831855f * var);
+    const int64_t row_base = (int64_t)(a.net_A ? a.net_A[r] : r) * a.D;
+    // A wave owns segments wave, wave + 4, ...; it takes them kSegBatch at a time and issues every load of
+    // a batch -- the offset table first, then the network output, the target and the base -- before it
+    // touches the first value: one table round trip and one memory round trip per batch, not per segment.
+    for (int sg0 = wave; sg0 < nseg; sg0 += kWaves * kSegBatch) {
+        int4 o4[kSegBatch];
+        bool full[kSegBatch];
+#pragma unroll
+        for (int b = 0; b < kSegBatch; ++b) {
+            const int j0 = (sg0 + b * kWaves) * 256 + lane * 4;
+            full[b] = j0 + 3 < d;                      // false for every lane of a segment past the end
+            if (full[b]) o4[b] = *(const int4*)(offt + j0);
+        }
+        float s[kSegBatch][4];
+        f4u tg[kSegBatch], b4[kSegBatch];
+#pragma unroll
+        for (int b = 0; b < kSegBatch; ++b) {
+            const int j0 = (sg0 + b * kWaves) * 256 + lane * 4;
+            if (full[b]) {
+                const int o[4] = {o4[b].x, o4[b].y, o4[b].z, o4[b].w};
+                const bool contig = __all(o[3] - o[0] == 3);  // over the lanes in this branch
+                net_at4<NETDT>(a.net, row_base, o, contig, s[b]);
+                tg[b] = *(const f4u*)(a.v + j0);       // rows of a (T+1, d) path: dword aligned only
+                b4[b] = *(const f4u*)(basep + j0);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < kSegBatch; ++b) {
+            const int sg = sg0 + b * kWaves;
+            if (sg >= nseg) break;                     // wave-uniform
+            const int j0 = sg * 256 + lane * 4;
+            float t[4];
+            if (full[b]) {
+                const float bb[4] = {b4[b].x, b4[b].y, b4[b].z, b4[b].w};
+                const float g[4] = {tg[b].x, tg[b].y, tg[b].z, tg[b].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dr = em_drift<MODE>(a.cx, a.cs, bb[k], s[b][k]);
+                    const float m = bb[k] + dr * a.dt;
+                    const float df = g[k] - m;
+                    const float q = (df * df) / var;
+                    t[k] = (lognorm + q) * -0.5f;
+                }
+            } else {                                   // the row's ragged tail: at most one lane per row
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    t[k] = 0.0f;
+                    if (j0 + k < d) {
+                        const float sv = net_at<NETDT>(a.net, row_base + offt[j0 + k]);
+                        const float bv = basep[j0 + k];
+                        const float dr = em_drift<MODE>(a.cx, a.cs, bv, sv);
+                        const float m = bv + dr * a.dt;
+                        const float df = a.v[j0 + k] - m;
+                        const float q = (df * df) / var;
+                        t[k] = (lognorm + q) * -0.5f;
+                    }
+                }
+            }
+            float sum = (t[0] + t[1]) + (t[2] + t[3]);
+            TreePath path;  // the sibling records are not needed here; the compiler drops them
+            sum = wave_upsweep(sum, path);
+            if (lane == 0) seg[sg] = sum;
+        }
+    }
+    __syncthreads();
+    float root = 0.0f;
+    if (nseg <= 64) {
+        if (wave == 0) {
+            float x = lane < nseg ? seg[lane] : 0.0f;
+            TreePath path;
+            root = wave_upsweep(x, path);
+        }
+    } else {
+        // pairwise levels in LDS, ping-pong between the two halves of `seg` (2 * nseg floats)
+        float* cur = seg;
+        float* nxt = seg + nseg;
+        int m = nseg;
+        while (m > 1) {
+            const int h = m >> 1;
+            for (int i = threadIdx.x; i < h; i += kBlock) nxt[i] = cur[2 * i] + cur[2 * i + 1];
+            if ((m & 1) && threadIdx.x == 0) nxt[h] = cur[m - 1];
+            m = h + (m & 1);
+            __syncthreads();
+            float* tsw = cur; cur = nxt; nxt = tsw;
+        }
+        root = cur[0];
+    }
+    return root;
+}
+
+// Which role workgroup b plays: proposal groups are spread evenly among the log-density groups.
+__device__ __forceinline__ bool em_role(int b, int nU, int total, int& index) {
+    const int u0 = (int)(((int64_t)b * nU) / total);
+    const int u1 = (int)(((int64_t)(b + 1) * nU) / total);
+    const bool is_u = u1 != u0;
+    index = is_u ? u0 : b - u0;
+    return is_u;
+}
+
+// PAIR: the launch covers the whole draw (row0 == 0, n == n_total): a proposal thread owns flat elements
+// i..i+3 and i+half..i+half+3, the two words of the same block-cipher calls.
+template <bool PAIR, bool VEC, int NETDT, int MODE>
+__global__ void __launch_bounds__(kBlock, FBSMI_EM_WAVES) k_em_finish(const EmArgs a) {
+    extern __shared__ float seg[];
+    int index;
+    const bool is_u = em_role(blockIdx.x, a.nU, a.nU + a.nV, index);
+    if (is_u) {
+        const uint32_t g = (uint32_t)index * kBlock + threadIdx.x;
+        if (PAIR) {
+            const uint32_t i0 = 4u * g;
+            if (i0 >= a.half) return;
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = i0 + k, j = i + a.half;
+                threefry2x32(a.k0, a.k1, i, j < a.ntot_el ? j : 0u, lo[k], hi[k]);
+            }
+            em_u_group<VEC, NETDT, MODE>(a, i0, a.half, lo);
+            em_u_group<VEC, NETDT, MODE>(a, i0 + a.half, a.ntot_el, hi);
+        } else {
+            const uint32_t l0 = 4u * g;
+            if (l0 >= a.nloc_el) return;
+            const uint32_t e0 = a.first_el + l0;
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = random_bits_at(a.k0, a.k1, a.ntot_el, (uint64_t)e0 + k);
+            em_u_group<VEC, NETDT, MODE>(a, e0, a.first_el + a.nloc_el, w);
+        }
+    } else {
+        const float root = em_row_logpdf<NETDT, MODE, 0>(a, index, seg);
+        if (threadIdx.x == 0) a.lw[index] = root;
+    }
+}
+
+template <int NETDT, int MODE>
+__global__ void __launch_bounds__(kBlock) k_em_translp(const EmArgs a) {
+    extern __shared__ float seg[];
+    const float root = em_row_logpdf<NETDT, MODE, 1>(a, blockIdx.x, seg);
+    if (threadIdx.x == 0) a.lw[blockIdx.x] = root;
+}
+
+// img[r][e] = role[e] >= 0 ? us[A[r]][role[e]] : v_prev[~role[e]]; one workgroup = (row, 1024-element chunk)
+template <int OUTDT, bool VEC>
+__global__ void __launch_bounds__(kBlock) k_em_concat(const float* __restrict__ us, const int32_t* __restrict__ A,
+                                                     const float* __restrict__ v_prev, const int32_t* __restrict__ role,
+                                                     int32_t du, int32_t D, int32_t chunks, void* img) {
+    const int32_t r = blockIdx.x / chunks, c = blockIdx.x - r * chunks;
+    const int e0 = c * 1024 + threadIdx.x * 4;
+    if (e0 >= D) return;
+    const float* __restrict__ row = us + (int64_t)(A ? A[r] : r) * du;
+    float x[4];
+    if (VEC) {
+        const int4 ro = *(const int4*)(role + e0);
+        const int o[4] = {ro.x, ro.y, ro.z, ro.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = o[k] >= 0 ? row[o[k]] : v_prev[~o[k]];
+        if (OUTDT == 0) {
+            *(float4*)((float*)img + (int64_t)r * D + e0) = make_float4(x[0], x[1], x[2], x[3]);
+        } else {
+            ushort4 h;
+            h.x = f32_to_bf16(x[0]); h.y = f32_to_bf16(x[1]); h.z = f32_to_bf16(x[2]); h.w = f32_to_bf16(x[3]);
+            *(ushort4*)((unsigned short*)img + (int64_t)r * D + e0) = h;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (e0 + k < D) {
+                const int o = role[e0 + k];
+                const float xv = o >= 0 ? row[o] : v_prev[~o];
+                if (OUTDT == 0) ((float*)img)[(int64_t)r * D + e0 + k] = xv;
+                else ((unsigned short*)img)[(int64_t)r * D + e0 + k] = f32_to_bf16(xv);
+            }
+        }
+    }
+}
+
+#define FBSMI_NEED(cond, msg) \
+    if (!(cond)) return fail(FBSMI_ERR_ARG, msg)
+#define FBSMI_LAUNCH_CHECK()                                                     \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e_)); \
+    } while (0)
+
+template <bool PAIR, bool VEC>
+int launch_finish(const EmArgs& a, int net_dtype, int mode, size_t lds, hipStream_t st) {
+    const dim3 grid((unsigned)(a.nU + a.nV));
+    if (net_dtype == 0 && mode == 0) k_em_finish<PAIR, VEC, 0, 0><<<grid, kBlock, lds, st>>>(a);
+    else if (net_dtype == 0) k_em_finish<PAIR, VEC, 0, 1><<<grid, kBlock, lds, st>>>(a);
+    else if (mode == 0) k_em_finish<PAIR, VEC, 1, 0><<<grid, kBlock, lds, st>>>(a);
+    else k_em_finish<PAIR, VEC, 1, 1><<<grid, kBlock, lds, st>>>(a);
+    FBSMI_LAUNCH_CHECK();
+    return FBSMI_OK;
+}
+
+size_t seg_lds_bytes(int d) {
+    const int nseg = (d + 255) >> 8;
+    return sizeof(float) * (size_t)(nseg <= 64 ? 64 : 2 * nseg);
+}
+
+bool mask_ok(const fbsmi_em_mask* m) {
+    return m && m->du >= 1 && m->dv >= 0 && m->u_off && (m->dv == 0 || m->v_off) && m->role;
+}
+
+}  // namespace
+
+}  // namespace fbsmi
+
+using namespace fbsmi;
+
+extern "C" {
+
+int fbsmi_em_concat(const fbsmi_em_mask* mask, const float* us, const int32_t* A, const float* v_prev, int64_t n,
+                    int out_dtype, void* img, void* stream) {
+    FBSMI_NEED(mask_ok(mask) && n >= 0 && (out_dtype == 0 || out_dtype == 1), "em_concat: bad arguments");
+    if (n == 0) return FBSMI_OK;
+    FBSMI_NEED(us && img && (mask->dv == 0 || v_prev), "em_concat: null pointer");
+    const int32_t D = mask->du + mask->dv;
+    const int32_t chunks = (D + 1023) / 1024;
+    FBSMI_NEED(n * chunks < (int64_t)1 << 31, "em_concat: too many rows");
+    const bool vec = D % 4 == 0 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)mask->role & 15) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(n * chunks));
+#define FBSMI_CC(OD, V) \
+    k_em_concat<OD, V><<<grid, kBlock, 0, st>>>(us, A, v_prev, mask->role, mask->du, D, chunks, img)
+    if (out_dtype == 0) { if (vec) FBSMI_CC(0, true); else FBSMI_CC(0, false); }
+    else { if (vec) FBSMI_CC(1, true); else FBSMI_CC(1, false); }
+#undef FBSMI_CC
+    FBSMI_LAUNCH_CHECK();
+    return FBSMI_OK;
+}
+
+int fbsmi_em_finish(const fbsmi_em_mask* mask, const float* us, const int32_t* A, const void* net,
+                    const int32_t* net_A, int net_dtype, int mode, float cx, float cs, float dt, float sd, const float* v, const float* v_prev, uint32_t k0,
+                    uint32_t k1, int64_t n_total, int64_t row0, int64_t n, int64_t pin_row, const float* pin_value,
+                    float* us_new, float* lw, void* stream) {
+    FBSMI_NEED(mask_ok(mask) && n >= 0 && row0 >= 0 && row0 + n <= n_total && (net_dtype == 0 || net_dtype == 1) &&
+                   (mode == 0 || mode == 1), "em_finish: bad arguments");
+    if (n == 0 || (!us_new && !lw)) return FBSMI_OK;
+    FBSMI_NEED(net && n < ((int64_t)1 << 31), "em_finish: null network output or too many rows");
+    FBSMI_NEED(!us_new || (us && us_new != us), "em_finish: the proposal needs us, and us_new must not alias it");
+    FBSMI_NEED(!lw || mask->dv == 0 || (v && v_prev), "em_finish: the weights need v and v_prev");
+    FBSMI_NEED(pin_row < 0 || (pin_row < n && pin_value), "em_finish: bad pin");
+    FBSMI_NEED(n_total * (int64_t)mask->du < ((int64_t)1 << 32), "em_finish: the noise draw exceeds 2^32 elements");
+    EmArgs a;
+    a.us = us; a.A = A; a.net_A = net_A; a.net = net; a.v = v; a.v_prev = v_prev; a.pin_value = pin_value;
+    a.us_new = us_new; a.lw = lw; a.u_off = mask->u_off; a.v_off = mask->v_off;
+    a.du = mask->du; a.dv = mask->dv; a.D = mask->du + mask->dv;
+    a.cx = cx; a.cs = cs; a.dt = dt; a.sd = sd; a.k0 = k0; a.k1 = k1;
+    a.ntot_el = (uint32_t)(n_total * mask->du);
+    a.half = (uint32_t)(((uint64_t)a.ntot_el + 1) >> 1);
+    a.first_el = (uint32_t)(row0 * mask->du);
+    a.nloc_el = (uint32_t)(n * mask->du);
+    a.n = (int32_t)n;
+    a.pin_row = us_new && pin_row >= 0 ? (int32_t)pin_row : -1;
+    const bool pair = row0 == 0 && n == n_total;
+    const uint32_t groups = pair ? (a.half + 3) / 4 : (a.nloc_el + 3) / 4;
+    a.nU = us_new ? (int32_t)((groups + kBlock - 1) / kBlock) : 0;
+    a.nV = lw ? (int32_t)n : 0;
+    // 16-byte accesses on particle rows: whole rows of 4-float groups, aligned bases, and in the paired
+    // walk a second half that starts on a group boundary
+    const bool vec = mask->du % 4 == 0 && (!pair || a.half % 4 == 0) && (a.first_el % 4 == 0) &&
+                     ((((uintptr_t)us | (uintptr_t)us_new) & 15) == 0);
+    FBSMI_NEED((((uintptr_t)mask->u_off | (uintptr_t)mask->v_off) & 15) == 0,
+               "em_finish: the mask tables must be 16-byte aligned");
+    const size_t lds = seg_lds_bytes(mask->dv);
+    hipStream_t st = (hipStream_t)stream;
+    if (pair) return vec ? launch_finish<true, true>(a, net_dtype, mode, lds, st)
+                         : launch_finish<true, false>(a, net_dtype, mode, lds, st);
+    return vec ? launch_finish<false, true>(a, net_dtype, mode, lds, st)
+               : launch_finish<false, false>(a, net_dtype, mode, lds, st);
+}
+
+int fbsmi_em_transition_logpdf(const fbsmi_em_mask* mask, const float* us, const void* net, int net_dtype, int mode,
+                               float cx, float cs, float dt, float sd, const float* u, int64_t n, float* lw,
+                               void* stream) {
+    FBSMI_NEED(mask_ok(mask) && n >= 0 && (net_dtype == 0 || net_dtype == 1) && (mode == 0 || mode == 1),
+               "em_transition_logpdf: bad arguments");
+    if (n == 0) return FBSMI_OK;
+    FBSMI_NEED(us && net && u && lw && n < ((int64_t)1 << 31), "em_transition_logpdf: null pointer");
+    FBSMI_NEED(((uintptr_t)mask->u_off & 15) == 0, "em_transition_logpdf: the mask tables must be 16-byte aligned");
+    EmArgs a = {};
+    a.us = us; a.net = net; a.v = u; a.lw = lw; a.u_off = mask->u_off; a.v_off = mask->v_off;
+    a.du = mask->du; a.dv = mask->dv; a.D = mask->du + mask->dv;
+    a.cx = cx; a.cs = cs; a.dt = dt; a.sd = sd; a.n = (int32_t)n; a.pin_row = -1;
+    const size_t lds = seg_lds_bytes(mask->du);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)n);
+    if (net_dtype == 0 && mode == 0) k_em_translp<0, 0><<<grid, kBlock, lds, st>>>(a);
+    else if (net_dtype == 0) k_em_translp<0, 1><<<grid, kBlock, lds, st>>>(a);
+    else if (mode == 0) k_em_translp<1, 0><<<grid, kBlock, lds, st>>>(a);
+    else k_em_translp<1, 1><<<grid, kBlock, lds, st>>>(a);
+    FBSMI_LAUNCH_CHECK();
+    return FBSMI_OK;
+}
+
+}  // extern "C"

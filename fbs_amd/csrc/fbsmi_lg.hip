@@ -1256,8 +1256,8 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop2t(LgDev dd, int s) {
         if (r < d.du) {   // element mA * du + r is in the first half of the draw, its partner belongs to slot mA + N/2
             uint32_t lo_, hi_;
             random_bits_pair(t0, t1, (uint64_t)N * d.du, (uint64_t)mA * d.du + r, lo_, hi_);
-            xi[0][r] = fbsmi_bits_to_normal(lo_);
-            xi[1][r] = fbsmi_bits_to_normal(hi_);
+            xi[0][r] = normal_from_bits(lo_);
+            xi[1][r] = normal_from_bits(hi_);
         }
     }
     float last;
@@ -1423,8 +1423,8 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop2(LgDev dd, int s) {
         if (r < d.du) {   // element mA * du + r is in the first half of the draw, its partner belongs to slot mA + N/2
             uint32_t lo_, hi_;
             random_bits_pair(t0, t1, (uint64_t)N * d.du, (uint64_t)mA * d.du + r, lo_, hi_);
-            xi[0][r] = fbsmi_bits_to_normal(lo_);
-            xi[1][r] = fbsmi_bits_to_normal(hi_);
+            xi[0][r] = normal_from_bits(lo_);
+            xi[1][r] = normal_from_bits(hi_);
         }
     }
     reinterpret_cast<float4*>(heapW)[2 * threadIdx.x] = hw0;
@@ -1914,7 +1914,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
             }
 #pragma unroll
             for (int vv = 0; vv < 4; ++vv) {
-                const float z = fbsmi_bits_to_normal(bits[vv]);
+                const float z = normal_from_bits(bits[vv]);
                 xi[vv] = (row0 + vv < du && mo < N) ? z : 0.0f;
             }
         }

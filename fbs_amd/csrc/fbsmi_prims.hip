@@ -40,8 +40,8 @@ __global__ void k_random(uint32_t k0, uint32_t k1, uint64_t n, void* out) {
             ((float*)out)[i] = fbsmi_bits_to_unit(o0);
             if (j < n) ((float*)out)[j] = fbsmi_bits_to_unit(o1);
         } else if (MODE == 2) {
-            ((float*)out)[i] = fbsmi_bits_to_normal(o0);
-            if (j < n) ((float*)out)[j] = fbsmi_bits_to_normal(o1);
+            ((float*)out)[i] = normal_from_bits(o0);
+            if (j < n) ((float*)out)[j] = normal_from_bits(o1);
         } else {
             ((float*)out)[i] = -fbsmi_logf(fbsmi_bits_to_unit(o0));
             if (j < n) ((float*)out)[j] = -fbsmi_logf(fbsmi_bits_to_unit(o1));
@@ -57,7 +57,7 @@ __global__ void k_random_range(uint32_t k0, uint32_t k1, uint64_t n_total, uint6
         const uint32_t b = random_bits_at(k0, k1, n_total, start + i);
         if (MODE == 0) ((uint32_t*)out)[i] = b;
         else if (MODE == 1) ((float*)out)[i] = fbsmi_bits_to_unit(b);
-        else ((float*)out)[i] = fbsmi_bits_to_normal(b);
+        else ((float*)out)[i] = normal_from_bits(b);
     }
 }
 
@@ -77,7 +77,8 @@ __global__ void k_math_map(int op, const float* x, const float* y, int64_t n, fl
             case 3: r = fbsmi_erfinvf(v); break;
             case 4: r = fbsmi_sqrtf(v); break;
             case 5: r = v / y[i]; break;
-            default: r = fbsmi_bits_to_normal(fbsmi_f2u(v)); break;
+            case 6: r = fbsmi_bits_to_normal(fbsmi_f2u(v)); break;  // the definition
+            default: r = normal_from_bits(fbsmi_f2u(v)); break;     // the form the kernels use (fbsmi_device.h)
         }
         out[i] = r;
     }
@@ -623,7 +624,7 @@ int fbsmi_randint(uint32_t k0, uint32_t k1, int64_t n, int32_t lo, int32_t hi, i
 }
 
 int fbsmi_math_map(int op, const float* x, const float* y, int64_t n, float* out, void* stream) {
-    if (n < 0 || op < 0 || op > 6 || (n > 0 && (!x || !out)) || (op == 5 && !y))
+    if (n < 0 || op < 0 || op > 7 || (n > 0 && (!x || !out)) || (op == 5 && !y))
         return fail(FBSMI_ERR_ARG, "math_map: bad arguments");
     if (n == 0) return FBSMI_OK;
     k_math_map<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(op, x, y, n, out);

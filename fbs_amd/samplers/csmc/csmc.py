@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from ... import ops
+from ...score import bridge_of
 
 
 def _bs_list(bs_star):
@@ -43,14 +44,22 @@ def _forward(key, us_star, bs_star, vs, ts, init_sampler, init_likelihood_logpdf
     log_ws = ops.normalise(init_likelihood_logpdf(vs[0], us, vs[1], **kwargs), log_space=True)  # :154-155
     keys = ops.split(key_scan, nsteps)                                             # :157
     As, log_wss, uss = [], [log_ws], [us]
+    # closures of one fbs_amd.score.ScoreBridge: gather, proposal, pin and weights of a step are two
+    # kernels around one network evaluation (fbsmi_em_concat / fbsmi_em_finish)
+    sb = bridge_of(transition_sampler, likelihood_logpdf) if set(kwargs) == {"mask_"} else None
     for k in range(nsteps):                                                        # scan_body :132-148
         key_resampling, key_transition = ops.split(keys[k], 2)
         v, v_prev, t_prev = vs[k + 1], vs[k], ts[k]
         A = cond_resampling(key_resampling, ops.math_map("exp", log_ws), bs[k], bs[k + 1], True)  # :139
-        us_prev = ops.take_rows(us, A)                                             # :140
-        us = transition_sampler(us_prev, v_prev, t_prev, key_transition, **kwargs)  # :142
-        us = ops.set_row(us, bs[k + 1], us_star[k + 1])                            # :143
-        log_ws = ops.normalise(likelihood_logpdf(v, us_prev, v_prev, t_prev, **kwargs), log_space=True)  # :145-146
+        if sb is not None:                                                         # :140-145 fused
+            us, lw = sb.fused_step(us, A, v, v_prev, t_prev, key_transition, kwargs["mask_"],
+                                   pin=(bs[k + 1], us_star[k + 1]))
+            log_ws = ops.normalise(lw, log_space=True)                             # :146
+        else:
+            us_prev = ops.take_rows(us, A)                                         # :140
+            us = transition_sampler(us_prev, v_prev, t_prev, key_transition, **kwargs)  # :142
+            us = ops.set_row(us, bs[k + 1], us_star[k + 1])                        # :143
+            log_ws = ops.normalise(likelihood_logpdf(v, us_prev, v_prev, t_prev, **kwargs), log_space=True)  # :145-146
         if store:
             As.append(A)
             log_wss.append(log_ws)

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from ..score import bridge_of
 from . import resampling as _resampling
 from .common import MCMCState
 
@@ -46,15 +47,25 @@ def bootstrap_filter(transition_sampler, measurement_cond_pdf, vs, ts, init_samp
     log_nell = torch.zeros((), dtype=torch.float32, device=us_prev.device)
     logn = np.float32(math.log(nparticles))
     filtering = [us_prev]
+    # closures of one ScoreBridge (log weights): one network evaluation per step, and with return_last the
+    # resampling gather of step k is folded into the network-input kernel of step k + 1
+    sb = bridge_of(transition_sampler, measurement_cond_pdf) if (log and set(kwargs) == {"mask_"}) else None
+    pending = None                                                                  # ancestors not gathered yet
     for k in range(nsteps):                                                         # scan_body :58-74
         key_proposal, key_resampling = ops.split(keys[k], 2)
         v, v_prev, t_prev = vs[k + 1], vs[k], ts[k]
-        us = transition_sampler(us_prev, v_prev, t_prev, key_proposal, **kwargs)    # :63
-        log_weights = measurement_cond_pdf(v, us_prev, v_prev, t_prev, **kwargs)    # :65
+        if sb is not None:
+            us, log_weights = sb.fused_step(us_prev, pending, v, v_prev, t_prev, key_proposal, kwargs["mask_"])
+        else:
+            us = transition_sampler(us_prev, v_prev, t_prev, key_proposal, **kwargs)    # :63
+            log_weights = measurement_cond_pdf(v, us_prev, v_prev, t_prev, **kwargs)    # :65
         weights, c = ops.normalise(log_weights, log_space=False, return_lse=True)   # :66,68,69
         log_nell = log_nell - (c - logn)                                            # :67
         inds = resampling(weights, key_resampling)
-        us_prev = ops.take_rows(us, inds)                                           # :72
+        if sb is not None and return_last and k < nsteps - 1:
+            us_prev, pending = us, inds
+            continue
+        us_prev, pending = ops.take_rows(us, inds), None                            # :72
         if not return_last:
             filtering.append(us_prev)
     if return_last:
@@ -93,9 +104,20 @@ def pmcmc_filter_step(key, vs_bridge, u0s, ts, transition_sampler, likelihood_lo
     us = u0s
     log_ell = torch.zeros((), dtype=torch.float32, device=u0s.device)
     logn = np.float32(math.log(nparticles))
+    sb = bridge_of(transition_sampler, likelihood_logpdf) if set(kwargs) == {"mask_"} else None
     for k in range(nsteps):                                                         # scan_body :138-152
         key_proposal, key_resampling = ops.split(keys[k], 2)
         v, v_prev, t_prev = vs_bridge[k + 1], vs_bridge[k], ts[k]
+        if sb is not None:                                                          # :144-150, one network evaluation
+            cell = {}
+
+            def resample(lw):
+                w, cell["c"] = ops.normalise(lw, log_space=False, return_lse=True)
+                return resampling(w, key_resampling)
+
+            us, _, _ = sb.fused_weight_then_propose(us, v, v_prev, t_prev, key_proposal, kwargs["mask_"], resample)
+            log_ell = (log_ell - logn) + cell["c"]
+            continue
         log_ws = likelihood_logpdf(v, us, v_prev, t_prev, **kwargs)                 # :144
         w, c = ops.normalise(log_ws, log_space=False, return_lse=True)              # :145,147,148
         log_ell = (log_ell - logn) + c                                              # :146

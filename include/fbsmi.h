@@ -52,7 +52,8 @@ int fbsmi_random_range(int mode, uint32_t k0, uint32_t k1, int64_t n_total, int6
                        void* stream);
 
 /* ---- numeric specification probes (include/fbsmi_math.h evaluated on the device) ------------
- * op: 0 exp, 1 log, 2 log1p, 3 erfinv, 4 sqrt, 5 x/y, 6 bits->normal (x reinterpreted as uint32). */
+ * op: 0 exp, 1 log, 2 log1p, 3 erfinv, 4 sqrt, 5 x/y, 6 bits->normal (x reinterpreted as uint32), 7 the same
+ * through the kernels' branch-free device form (must equal 6 bit for bit on every input). */
 int fbsmi_math_map(int op, const float* x, const float* y, int64_t n, float* out, void* stream);
 
 /* ---- tree reductions / scans -------------------------------------------------------------- */
@@ -184,6 +185,55 @@ int fbsmi_lg_filter_create(const fbsmi_lg_model* model, int32_t nparticles, int 
 void fbsmi_lg_filter_destroy(fbsmi_lg_filter* f);
 int fbsmi_lg_filter_run(fbsmi_lg_filter* f, const uint32_t* keys, const float* vs, const float* u0s, float* uT,
                         float* loglik, float* path, int use_graph, void* stream);
+
+/* ---- fused SMC step for score-network models (image experiments) --------------------------------
+ * The three closures of experiments/imgs/inpainting.py:102-147 (and supr.py; sb_imgs/supr.py:80-127)
+ * wrap ONE network evaluation on the joint image concat(u, v) per SMC step (csmc.py:142,145 evaluate it
+ * twice on the same input).  Around that evaluation (PyTorch-ROCm, not part of this library) the step is
+ * two kernels:
+ *   fbsmi_em_concat : ancestor gather (csmc.py:140) + ImageRestore.concat (fbs/data/images.py:355-363)
+ *                     -> the network's input, written once in the network's dtype;
+ *   fbsmi_em_finish : ImageRestore.unpack of the network output (images.py:333-353), reverse drift
+ *                     (inpainting.py:102-103), Euler-Maruyama proposal with in-kernel
+ *                     jax.random.normal (inpainting.py:122-128), reference pin (csmc.py:143) and the
+ *                     row-summed Gaussian log-density of the observed increment (inpainting.py:141-147).
+ * A particle row holds du unobserved floats (p, c) -> p*c + channel; an image holds D = du + dv floats
+ * (w, h, c) row-major.  The mask is three int32 device tables:
+ *   u_off (du): image offset of unobserved element j;  v_off (dv): image offset of observed element j;
+ *   role (D): inverse map, role[e] = j >= 0 if image element e is unobserved element j, ~j < 0 if it is
+ *   observed element j.                                                                              */
+typedef struct fbsmi_em_mask {
+    int32_t du, dv;
+    const int32_t* u_off;
+    const int32_t* v_off;
+    const int32_t* role;
+} fbsmi_em_mask;
+
+/* img[r] = concat(us[A[r]], v_prev) for n rows; A nullable (identity).  out_dtype 0 float32, 1 bfloat16
+ * (round to nearest even).  us (rows, du), v_prev (dv), img (n, D). */
+int fbsmi_em_concat(const fbsmi_em_mask* mask, const float* us, const int32_t* A, const float* v_prev, int64_t n,
+                    int out_dtype, void* img, void* stream);
+
+/* net: the network evaluated on fbsmi_em_concat's output, (rows, D); net_dtype 0 float32, 1 bfloat16.  Row r of
+ * this call uses net[net_A[r]] (net_A nullable: net[r]) -- pmcmc_filter_step (fbs/samplers/smc.py:144-150)
+ * weights the particles, resamples, and proposes from the SAME network input rows, gathered.
+ * mode 0: reverse drift = cx * x + cs * net (score model: cx = -a(T - t), cs = b(T - t)^2, inpainting.py:102-103);
+ * mode 1: reverse drift = net (Schrodinger-bridge backward drift, sb_imgs/supr.py:84-85).
+ * With x = us[A[r]] (A nullable), z = rows [row0, row0 + n) of jax.random.normal(key, (n_total, du)):
+ *   us_new[r] = (x + drift_u * dt) + sd * z;   us_new[pin_row] = pin_value (pin_row < 0: no pin);
+ *   lw[r] = tree-sum_j ( log(2 pi sd^2) + (v[j] - (v_prev[j] + drift_v[j] * dt))^2 / sd^2 ) / -2
+ * (jax.scipy.stats.norm.logpdf summed in the canonical pairwise order of include/fbsmi_math.h).
+ * us_new (n, du) nullable (no proposal), lw (n) nullable (no weights); us_new must not alias us. */
+int fbsmi_em_finish(const fbsmi_em_mask* mask, const float* us, const int32_t* A, const void* net,
+                    const int32_t* net_A, int net_dtype, int mode, float cx, float cs, float dt, float sd, const float* v, const float* v_prev, uint32_t k0,
+                    uint32_t k1, int64_t n_total, int64_t row0, int64_t n, int64_t pin_row, const float* pin_value,
+                    float* us_new, float* lw, void* stream);
+
+/* transition_logpdf (inpainting.py:131-138): lw[r] = sum_j norm.logpdf(u[j]; us[r][j] + drift_u[r][j] * dt, sd)
+ * for the n rows of us (n, du) and the network output net (n, D) on concat(us, v_prev); u (du). */
+int fbsmi_em_transition_logpdf(const fbsmi_em_mask* mask, const float* us, const void* net, int net_dtype, int mode,
+                               float cx, float cs, float dt, float sd, const float* u, int64_t n, float* lw,
+                               void* stream);
 
 /* HIP-event timing hooks: average duration in microseconds of the propagate ("Euler") kernel
  * over the launches since the last reset; 0 launches -> returns 0. Only measured when

@@ -254,6 +254,17 @@ def sqrt(x):
     return _map1("orc_sqrt", x)
 
 
+def bits_to_normal(bits) -> np.ndarray:
+    """fbsmi_bits_to_normal (include/fbsmi_math.h) on an array of random words: jax.random.normal's map
+    u = max(lo, unit * (hi - lo) + lo), sqrt(2) * erf_inv(u), one float32 rounding per operation."""
+    b = np.ascontiguousarray(bits, np.uint32)
+    unit = ((b >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1.0)
+    lo = np.float32(-0.99999994)
+    u = (unit * np.float32(2.0)).astype(np.float32) + lo
+    u = np.where(u < lo, lo, u).astype(np.float32)
+    return (np.float32(1.41421354) * erfinv(u)).astype(np.float32)
+
+
 def div(x, y):
     x, y = _f32(x), _f32(y)
     out = np.zeros_like(x)

@@ -187,3 +187,21 @@ def test_no_cpu_fallback():
     from fbs_amd import ops
     with pytest.raises(RuntimeError):
         ops.cumsum(torch.ones(8))
+
+
+def test_kernel_normal_equals_the_definition_on_all_2_23_arguments(oracle, dev):
+    """normal_from_bits (fbs_amd/csrc/fbsmi_device.h), the branch-free form every kernel draws its noise with, against
+    fbsmi_bits_to_normal (include/fbsmi_math.h) evaluated on the device and by the C oracle: jax.random.normal uses the
+    top 23 bits of a random word, so these are ALL the values the sampler can ever draw."""
+    from fbs_amd import ops
+    m = torch.arange(1 << 23, dtype=torch.int64, device=dev)
+    for low in (0, 0x1FF):                                         # the 9 discarded bits must not matter
+        bits = ((m << 9) | low).to(torch.int32)                    # wraps to the same 32-bit pattern
+        words = bits.view(torch.float32)
+        a = ops.math_map("bits_to_normal", words)
+        b = ops.math_map("bits_to_normal_kernel", words)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    want = oracle.bits_to_normal((np.arange(1 << 23, dtype=np.uint64) << np.uint64(9)).astype(np.uint32))
+    got = b.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.isfinite(got).all() and abs(float(got.mean())) < 1e-3 and abs(float(got.std()) - 1.0) < 1e-3
