@@ -96,6 +96,22 @@ __device__ __forceinline__ float div_lean(float a, float b) {
     return __builtin_fmaf(rem, r, q);
 }
 
+// a / b for many a and one b, rb = 1.0f / b correctly rounded (Markstein): two rounds of residual correction give
+// the correctly rounded quotient as long as nothing underflows or overflows on the way -- div_by_in_range(a) for
+// moderate b (the caller's b is a variance, sd^2 with sd = sqrt(dt) * dispersion); 5 instructions against the 11 of
+// the range-proof sequence, one of them v_rcp_f32.  tests/test_gpu_primitives.py compares it with `/` on 2^26 pairs.
+__device__ __forceinline__ float div_by(float a, float b, float rb) {
+    float q = a * rb;
+    float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, rb, q);
+    r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, rb, q);
+}
+// |a| in [2^-60, 2^60]
+__device__ __forceinline__ bool div_by_in_range(float a) {
+    return ((fbsmi_f2u(a) & 0x7fffffffu) - 0x21800000u) <= (0x5d800000u - 0x21800000u);
+}
+
 __device__ __forceinline__ float normal_from_bits(uint32_t bits) {
     const float lo = -0.99999994f;
     float x = fbsmi_bits_to_unit(bits) * 2.0f + lo;            // fbsmi_bits_to_normal
@@ -143,8 +159,10 @@ __device__ __forceinline__ float normal_from_bits(uint32_t bits) {
     }
     return 1.41421354f * (p * x);
 }
-#else
+#else  // host pass of hipcc: never executed, kept so that device functions parse
 __host__ __device__ __forceinline__ float normal_from_bits(uint32_t bits) { return fbsmi_bits_to_normal(bits); }
+__host__ __device__ __forceinline__ float div_by(float a, float b, float) { return a / b; }
+__host__ __device__ __forceinline__ bool div_by_in_range(float) { return false; }
 #endif
 
 __host__ __device__ __forceinline__ float normal_at(uint32_t k0, uint32_t k1, uint64_t n, uint64_t i) {

@@ -36,12 +36,14 @@ namespace {
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));           // 16-byte load, dword aligned
 typedef unsigned short us4u __attribute__((ext_vector_type(4), aligned(2)));  // four bf16, 2-byte aligned
 
-#ifndef FBSMI_EM_SEGBATCH
-#define FBSMI_EM_SEGBATCH 2
+// FBSMI_EM_PROBE (diagnostic builds, tools/build_variants.sh; results are WRONG): 1 no erf_inv, 2 no Threefry and no
+// erf_inv, 3 log-density role without its arithmetic, 4 proposal role without its global loads
+#ifndef FBSMI_EM_PROBE
+#define FBSMI_EM_PROBE 0
 #endif
-constexpr int kSegBatch = FBSMI_EM_SEGBATCH;  // 256-element segments a wave keeps in flight (log-density role)
+
 #ifndef FBSMI_EM_WAVES
-#define FBSMI_EM_WAVES 6  // waves per SIMD the finish kernel is compiled for (80 registers: no spills)
+#define FBSMI_EM_WAVES 8  // waves per SIMD the finish kernel is compiled for (56 registers used)
 #endif
 
 struct EmArgs {
@@ -83,20 +85,35 @@ __device__ __forceinline__ float net_at(const void* net, int64_t idx) {
     return bf16_to_f32(((const unsigned short*)net)[idx]);
 }
 
-// four network values at offsets o[0..3] of a row; `contig` (wave-uniform) = every lane's offsets are consecutive
+// Four network values at offsets o[0..3] of a row (row_base + o[k] inside the buffer, D floats per row).  Loads under
+// a DIVERGENT branch cost a full drain of the wave's memory queue at the branch's end on this compiler (it parks an
+// s_waitcnt vmcnt(0) where the loaded registers meet the other path's), so nothing here is predicated per lane: every
+// lane issues one 16-byte load at min(o[0], D - 4), which is the four values whenever its offsets are consecutive
+// (inside a run of the mask); if ANY lane of the wave has a group across two runs the whole wave also issues the four
+// element loads (a wave-uniform branch) and each lane picks.  The address unit takes four lanes per cycle whatever the
+// width, so a dword gather costs as much as a 16-byte one: wide loads are the point.
 template <int NETDT>
-__device__ __forceinline__ void net_at4(const void* net, int64_t row_base, const int (&o)[4], bool contig, float (&s)[4]) {
-    if (contig) {
-        if (NETDT == 0) {
-            const f4u t = *(const f4u*)((const float*)net + row_base + o[0]);
-            s[0] = t.x; s[1] = t.y; s[2] = t.z; s[3] = t.w;
-        } else {
-            const us4u t = *(const us4u*)((const unsigned short*)net + row_base + o[0]);
-            s[0] = bf16_to_f32(t.x); s[1] = bf16_to_f32(t.y); s[2] = bf16_to_f32(t.z); s[3] = bf16_to_f32(t.w);
-        }
+__device__ __forceinline__ void net_at4(const void* net, int64_t row_base, int D, const int (&o)[4], bool lane_valid,
+                                        float (&s)[4]) {
+    const bool contig = o[3] - o[0] == 3;
+    const int wb = o[0] < D - 4 ? o[0] : D - 4;   // == o[0] when contig
+    float w[4];
+    if (NETDT == 0) {
+        const f4u t = *(const f4u*)((const float*)net + row_base + wb);
+        w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+    } else {
+        const us4u t = *(const us4u*)((const unsigned short*)net + row_base + wb);
+        w[0] = bf16_to_f32(t.x); w[1] = bf16_to_f32(t.y); w[2] = bf16_to_f32(t.z); w[3] = bf16_to_f32(t.w);
+    }
+    if (__any(lane_valid && !contig)) {
+        float nv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nv[k] = net_at<NETDT>(net, row_base + o[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = contig ? w[k] : nv[k];
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] = net_at<NETDT>(net, row_base + o[k]);
+        for (int k = 0; k < 4; ++k) s[k] = w[k];
     }
 }
 
@@ -112,51 +129,70 @@ __device__ __forceinline__ float em_drift(float cx, float cs, float x, float s) 
 // their four random words.  VEC: du % 4 == 0 and e0 % 4 == 0, so the four sit in one row, 16-byte
 // aligned.
 // ------------------------------------------------------------------------------------------------
-template <bool VEC, int NETDT, int MODE>
-__device__ __forceinline__ void em_u_group(const EmArgs& a, uint32_t e0, uint32_t lim, const uint32_t (&bits)[4]) {
+struct UGroup {  // operands of four consecutive elements of one row (VEC walk)
+    uint32_t r, p;
+    float x[4], s[4];
+};
+
+template <int NETDT>
+__device__ __forceinline__ void em_u_load(const EmArgs& a, uint32_t e0, UGroup& g) {
+    const uint32_t le = e0 - a.first_el;
+    const uint32_t du = (uint32_t)a.du;
+    g.r = le / du;
+    g.p = le - g.r * du;
+    if (FBSMI_EM_PROBE == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { g.x[k] = (float)g.p; g.s[k] = (float)g.r; }
+        return;
+    }
+    const int64_t src = a.A ? (int64_t)a.A[g.r] : (int64_t)g.r;
+    const int4 o4 = *(const int4*)(a.u_off + g.p);
+    const float4 x4 = *(const float4*)(a.us + src * du + g.p);
+    const int o[4] = {o4.x, o4.y, o4.z, o4.w};
+    net_at4<NETDT>(a.net, (int64_t)(a.net_A ? a.net_A[g.r] : (int32_t)g.r) * a.D, a.D, o, true, g.s);
+    g.x[0] = x4.x; g.x[1] = x4.y; g.x[2] = x4.z; g.x[3] = x4.w;
+}
+
+template <int NETDT, int MODE>
+__device__ __forceinline__ void em_u_store(const EmArgs& a, const UGroup& g, const uint32_t (&bits)[4]) {
+    float y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float z = (FBSMI_EM_PROBE == 1 || FBSMI_EM_PROBE == 2) ? fbsmi_u2f(bits[k] >> 9) : normal_from_bits(bits[k]);
+        const float d = em_drift<MODE>(a.cx, a.cs, g.x[k], g.s[k]);
+        const float m = g.x[k] + d * a.dt;
+        const float nz = a.sd * z;
+        y[k] = m + nz;
+    }
+    float4 out = make_float4(y[0], y[1], y[2], y[3]);
+    if ((int32_t)g.r == a.pin_row) {
+        const f4u pv = *(const f4u*)(a.pin_value + g.p);
+        out = make_float4(pv.x, pv.y, pv.z, pv.w);
+    }
+    *(float4*)(a.us_new + (int64_t)g.r * a.du + g.p) = out;
+}
+
+// the same for any du and any alignment, element by element
+template <int NETDT, int MODE>
+__device__ __forceinline__ void em_u_scalar(const EmArgs& a, uint32_t e0, uint32_t lim, const uint32_t (&bits)[4]) {
     const uint32_t le = e0 - a.first_el;
     const uint32_t du = (uint32_t)a.du;
     uint32_t r = le / du, p = le - r * du;
-    if (VEC) {
-        const int64_t src = a.A ? (int64_t)a.A[r] : (int64_t)r;
-        const float4 x4 = *(const float4*)(a.us + src * du + p);
-        const int4 o4 = *(const int4*)(a.u_off + p);
-        const int o[4] = {o4.x, o4.y, o4.z, o4.w};
-        const float x[4] = {x4.x, x4.y, x4.z, x4.w};
-        float s[4], y[4];
-        const bool contig = __all(o[3] - o[0] == 3);
-        net_at4<NETDT>(a.net, (int64_t)(a.net_A ? a.net_A[r] : (int32_t)r) * a.D, o, contig, s);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 4; ++k) {
+        if (e0 + k < lim) {
+            const int64_t src = a.A ? (int64_t)a.A[r] : (int64_t)r;
+            const float x = a.us[src * du + p];
+            const float s = net_at<NETDT>(a.net, (int64_t)(a.net_A ? a.net_A[r] : (int32_t)r) * a.D + a.u_off[p]);
             const float z = normal_from_bits(bits[k]);
-            const float d = em_drift<MODE>(a.cx, a.cs, x[k], s[k]);
-            const float m = x[k] + d * a.dt;
+            const float d = em_drift<MODE>(a.cx, a.cs, x, s);
+            const float m = x + d * a.dt;
             const float nz = a.sd * z;
-            y[k] = m + nz;
+            float y = m + nz;
+            if ((int32_t)r == a.pin_row) y = a.pin_value[p];
+            a.us_new[(int64_t)r * du + p] = y;
         }
-        float4 out = make_float4(y[0], y[1], y[2], y[3]);
-        if ((int32_t)r == a.pin_row) {
-            const f4u pv = *(const f4u*)(a.pin_value + p);
-            out = make_float4(pv.x, pv.y, pv.z, pv.w);
-        }
-        *(float4*)(a.us_new + (int64_t)r * du + p) = out;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (e0 + k < lim) {
-                const int64_t src = a.A ? (int64_t)a.A[r] : (int64_t)r;
-                const float x = a.us[src * du + p];
-                const float s = net_at<NETDT>(a.net, (int64_t)(a.net_A ? a.net_A[r] : (int32_t)r) * a.D + a.u_off[p]);
-                const float z = normal_from_bits(bits[k]);
-                const float d = em_drift<MODE>(a.cx, a.cs, x, s);
-                const float m = x + d * a.dt;
-                const float nz = a.sd * z;
-                float y = m + nz;
-                if ((int32_t)r == a.pin_row) y = a.pin_value[p];
-                a.us_new[(int64_t)r * du + p] = y;
-            }
-            if (++p == du) { p = 0; ++r; }
-        }
+        if (++p == du) { p = 0; ++r; }
     }
 }
 
@@ -167,6 +203,19 @@ __device__ __forceinline__ void em_u_group(const EmArgs& a, uint32_t e0, uint32_
 // in the pairwise order of orc_sum (adjacent pairs, zero padded).  `seg` = LDS scratch of
 // max(64, segments) floats.  Every thread of the workgroup must call it; thread 0 returns the sum.
 // ------------------------------------------------------------------------------------------------
+// One 256-element segment of a row's log-density in flight: its offset words, then its operands.
+struct SegTab {
+    int4 o4;
+    int j0, jl;  // first element of the lane's group; the same clamped into the row (loads are never predicated)
+    bool full;   // the lane's four elements exist (false for every lane of a segment past the row's end)
+};
+struct SegOps {
+    float s[4];
+    f4u tg, b4;
+    int j0;
+    bool full;
+};
+
 template <int NETDT, int MODE, int PART>
 __device__ __forceinline__ float em_row_logpdf(const EmArgs& a, int32_t r, float* seg) {
     const int d = PART == 0 ? a.dv : a.du;
@@ -175,70 +224,106 @@ __device__ __forceinline__ float em_row_logpdf(const EmArgs& a, int32_t r, float
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nseg = (d + 255) >> 8;
     const float var = a.sd * a.sd;
+    const float rvar = 1.0f / var;  // for div_by(): every quotient of this row has the divisor var
     const float lognorm = fbsmi_logf(6.2831855f * var);
     const int64_t row_base = (int64_t)(a.net_A ? a.net_A[r] : r) * a.D;
-    // A wave owns segments wave, wave + 4, ...; it takes them kSegBatch at a time and issues every load of
-    // a batch -- the offset table first, then the network output, the target and the base -- before it
-    // touches the first value: one table round trip and one memory round trip per batch, not per segment.
-    for (int sg0 = wave; sg0 < nseg; sg0 += kWaves * kSegBatch) {
-        int4 o4[kSegBatch];
-        bool full[kSegBatch];
+    const int dl = d >= 4 ? ((d - 4) & ~3) : 0;   // last whole group of the row (the offset table has >= 4 entries: see launch)
+
+    auto table = [&](int sg) {      // stage 1: the segment's offset words
+        SegTab t;
+        t.j0 = sg * 256 + lane * 4;
+        t.full = sg < nseg && t.j0 + 3 < d;
+        t.jl = t.j0 < dl ? t.j0 : dl;
+        t.o4 = *(const int4*)(offt + t.jl);
+        return t;
+    };
+    auto issue = [&](const SegTab& t) {  // stage 2: network output (one 16-byte load inside a run of the mask, four loads
+        SegOps o;                        // for a group across two runs), target and base; nothing waits here
+        o.j0 = t.j0;
+        o.full = t.full;
+        const int of[4] = {t.o4.x, t.o4.y, t.o4.z, t.o4.w};
+        net_at4<NETDT>(a.net, row_base, a.D, of, t.full, o.s);
+        o.tg = *(const f4u*)(a.v + t.jl);          // rows of a (T+1, d) path: dword aligned only
+        o.b4 = *(const f4u*)(basep + t.jl);
+        return o;
+    };
+    auto compute = [&](const SegOps& o, int sg) {  // stage 3: the arithmetic, the wave's tree, the segment sum
+        float t[4];
+        if (o.full) {
+            const float bb[4] = {o.b4.x, o.b4.y, o.b4.z, o.b4.w};
+            const float g[4] = {o.tg.x, o.tg.y, o.tg.z, o.tg.w};
+            if (FBSMI_EM_PROBE == 3) {
 #pragma unroll
-        for (int b = 0; b < kSegBatch; ++b) {
-            const int j0 = (sg0 + b * kWaves) * 256 + lane * 4;
-            full[b] = j0 + 3 < d;                      // false for every lane of a segment past the end
-            if (full[b]) o4[b] = *(const int4*)(offt + j0);
-        }
-        float s[kSegBatch][4];
-        f4u tg[kSegBatch], b4[kSegBatch];
-#pragma unroll
-        for (int b = 0; b < kSegBatch; ++b) {
-            const int j0 = (sg0 + b * kWaves) * 256 + lane * 4;
-            if (full[b]) {
-                const int o[4] = {o4[b].x, o4[b].y, o4[b].z, o4[b].w};
-                const bool contig = __all(o[3] - o[0] == 3);  // over the lanes in this branch
-                net_at4<NETDT>(a.net, row_base, o, contig, s[b]);
-                tg[b] = *(const f4u*)(a.v + j0);       // rows of a (T+1, d) path: dword aligned only
-                b4[b] = *(const f4u*)(basep + j0);
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < kSegBatch; ++b) {
-            const int sg = sg0 + b * kWaves;
-            if (sg >= nseg) break;                     // wave-uniform
-            const int j0 = sg * 256 + lane * 4;
-            float t[4];
-            if (full[b]) {
-                const float bb[4] = {b4[b].x, b4[b].y, b4[b].z, b4[b].w};
-                const float g[4] = {tg[b].x, tg[b].y, tg[b].z, tg[b].w};
+                for (int k = 0; k < 4; ++k) t[k] = bb[k] + g[k] + o.s[k];
+            } else {
+                float sq[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float dr = em_drift<MODE>(a.cx, a.cs, bb[k], s[b][k]);
+                    const float dr = em_drift<MODE>(a.cx, a.cs, bb[k], o.s[k]);
                     const float m = bb[k] + dr * a.dt;
                     const float df = g[k] - m;
+                    sq[k] = df * df;
+                }
+                // (df * df) / var, correctly rounded: by the reciprocal when the wave's operands are in its range
+                const bool lean = __all(div_by_in_range(fmaxf(fmaxf(sq[0], sq[1]), fmaxf(sq[2], sq[3]))) &&
+                                        div_by_in_range(fminf(fminf(sq[0], sq[1]), fminf(sq[2], sq[3]))));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float q = lean ? div_by(sq[k], var, rvar) : sq[k] / var;
+                    t[k] = (lognorm + q) * -0.5f;
+                }
+            }
+        } else {                                   // the row's ragged tail: at most one lane per row
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t[k] = 0.0f;
+                if (o.j0 + k < d) {
+                    const float sv = net_at<NETDT>(a.net, row_base + offt[o.j0 + k]);
+                    const float bv = basep[o.j0 + k];
+                    const float dr = em_drift<MODE>(a.cx, a.cs, bv, sv);
+                    const float m = bv + dr * a.dt;
+                    const float df = a.v[o.j0 + k] - m;
                     const float q = (df * df) / var;
                     t[k] = (lognorm + q) * -0.5f;
                 }
-            } else {                                   // the row's ragged tail: at most one lane per row
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    t[k] = 0.0f;
-                    if (j0 + k < d) {
-                        const float sv = net_at<NETDT>(a.net, row_base + offt[j0 + k]);
-                        const float bv = basep[j0 + k];
-                        const float dr = em_drift<MODE>(a.cx, a.cs, bv, sv);
-                        const float m = bv + dr * a.dt;
-                        const float df = a.v[j0 + k] - m;
-                        const float q = (df * df) / var;
-                        t[k] = (lognorm + q) * -0.5f;
-                    }
-                }
             }
-            float sum = (t[0] + t[1]) + (t[2] + t[3]);
-            TreePath path;  // the sibling records are not needed here; the compiler drops them
-            sum = wave_upsweep(sum, path);
-            if (lane == 0) seg[sg] = sum;
         }
+        float sum = (t[0] + t[1]) + (t[2] + t[3]);
+        TreePath path;  // the sibling records are not needed here; the compiler drops them
+        sum = wave_upsweep(sum, path);
+        if (lane == 0) seg[sg] = sum;
+    };
+
+    // A wave owns segments wave, wave + 4, ...  The role is bound by memory latency, not by arithmetic (its time did not
+    // change when the arithmetic was removed), and a wave's loads retire in issue order, so the three stages are
+    // software-pipelined: while segment i is computed the operands of segment i + 1 and the offset words of segment
+    // i + 2 are in flight, and a wave never drains its queue before the last segment.
+    int sg = wave;
+    if (d < 4) {  // fewer elements than one group: the element-wise path only (wave-uniform)
+        SegOps none;
+        none.j0 = lane * 4;
+        none.full = false;
+        if (sg < nseg) compute(none, sg);
+        sg = nseg;
+    }
+    SegTab ta, tb;
+    SegOps oa, ob;
+    if (sg < nseg) {
+        ta = table(sg);
+        tb = table(sg + kWaves);
+        oa = issue(ta);
+    }
+    while (sg < nseg) {
+        ta = table(sg + 2 * kWaves);
+        ob = issue(tb);
+        compute(oa, sg);
+        sg += kWaves;
+        if (sg >= nseg) break;
+        tb = table(sg + 2 * kWaves);
+        oa = issue(ta);
+        compute(ob, sg);
+        sg += kWaves;
+        if (sg >= nseg) break;
     }
     __syncthreads();
     float root = 0.0f;
@@ -287,26 +372,41 @@ __global__ void __launch_bounds__(kBlock, FBSMI_EM_WAVES) k_em_finish(const EmAr
         if (PAIR) {
             const uint32_t i0 = 4u * g;
             if (i0 >= a.half) return;
+            UGroup g0, g1;
+            if (VEC) {  // every load of both groups is issued before the first random word is computed
+                em_u_load<NETDT>(a, i0, g0);
+                em_u_load<NETDT>(a, i0 + a.half, g1);
+            }
             uint32_t lo[4], hi[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t i = i0 + k, j = i + a.half;
-                threefry2x32(a.k0, a.k1, i, j < a.ntot_el ? j : 0u, lo[k], hi[k]);
+                if (FBSMI_EM_PROBE == 2) { lo[k] = i; hi[k] = j; }
+                else threefry2x32(a.k0, a.k1, i, j < a.ntot_el ? j : 0u, lo[k], hi[k]);
             }
-            em_u_group<VEC, NETDT, MODE>(a, i0, a.half, lo);
-            em_u_group<VEC, NETDT, MODE>(a, i0 + a.half, a.ntot_el, hi);
+            if (VEC) {
+                em_u_store<NETDT, MODE>(a, g0, lo);
+                em_u_store<NETDT, MODE>(a, g1, hi);
+            } else {
+                em_u_scalar<NETDT, MODE>(a, i0, a.half, lo);
+                em_u_scalar<NETDT, MODE>(a, i0 + a.half, a.ntot_el, hi);
+            }
         } else {
             const uint32_t l0 = 4u * g;
             if (l0 >= a.nloc_el) return;
             const uint32_t e0 = a.first_el + l0;
+            UGroup g0;
+            if (VEC) em_u_load<NETDT>(a, e0, g0);
             uint32_t w[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) w[k] = random_bits_at(a.k0, a.k1, a.ntot_el, (uint64_t)e0 + k);
-            em_u_group<VEC, NETDT, MODE>(a, e0, a.first_el + a.nloc_el, w);
+            if (VEC) em_u_store<NETDT, MODE>(a, g0, w);
+            else em_u_scalar<NETDT, MODE>(a, e0, a.first_el + a.nloc_el, w);
         }
     } else {
-        const float root = em_row_logpdf<NETDT, MODE, 0>(a, index, seg);
-        if (threadIdx.x == 0) a.lw[index] = root;
+        const int row = index;
+        const float root = em_row_logpdf<NETDT, MODE, 0>(a, row, seg);
+        if (threadIdx.x == 0) a.lw[row] = root;
     }
 }
 
@@ -317,38 +417,61 @@ __global__ void __launch_bounds__(kBlock) k_em_translp(const EmArgs a) {
     if (threadIdx.x == 0) a.lw[blockIdx.x] = root;
 }
 
-// img[r][e] = role[e] >= 0 ? us[A[r]][role[e]] : v_prev[~role[e]]; one workgroup = (row, 1024-element chunk)
+// img[r][e] = role[e] >= 0 ? us[A[r]][role[e]] : v_prev[~role[e]].  One workgroup = one row x kCatGroups chunks of
+// 1024 elements; a thread fetches the role words of all its chunks, then every source element, then stores: a few
+// KB in flight per wave, because a workgroup that moved 16 bytes per thread spent its life waiting (84 % of its wave
+// cycles, rocprofv3 SQ_WAIT_ANY) on two dependent round trips.
+constexpr int kCatGroups = 4;
+
 template <int OUTDT, bool VEC>
 __global__ void __launch_bounds__(kBlock) k_em_concat(const float* __restrict__ us, const int32_t* __restrict__ A,
                                                      const float* __restrict__ v_prev, const int32_t* __restrict__ role,
                                                      int32_t du, int32_t D, int32_t chunks, void* img) {
     const int32_t r = blockIdx.x / chunks, c = blockIdx.x - r * chunks;
-    const int e0 = c * 1024 + threadIdx.x * 4;
-    if (e0 >= D) return;
+    const int base = c * (1024 * kCatGroups) + threadIdx.x * 4;
     const float* __restrict__ row = us + (int64_t)(A ? A[r] : r) * du;
-    float x[4];
     if (VEC) {
-        const int4 ro = *(const int4*)(role + e0);
-        const int o[4] = {ro.x, ro.y, ro.z, ro.w};
+        int4 ro[kCatGroups];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = o[k] >= 0 ? row[o[k]] : v_prev[~o[k]];
-        if (OUTDT == 0) {
-            *(float4*)((float*)img + (int64_t)r * D + e0) = make_float4(x[0], x[1], x[2], x[3]);
-        } else {
-            ushort4 h;
-            h.x = f32_to_bf16(x[0]); h.y = f32_to_bf16(x[1]); h.z = f32_to_bf16(x[2]); h.w = f32_to_bf16(x[3]);
-            *(ushort4*)((unsigned short*)img + (int64_t)r * D + e0) = h;
-        }
+        for (int g = 0; g < kCatGroups; ++g)
+            if (base + g * 1024 < D) ro[g] = *(const int4*)(role + base + g * 1024);
+        float x[kCatGroups][4];
+#pragma unroll
+        for (int g = 0; g < kCatGroups; ++g)
+            if (base + g * 1024 < D) {
+                const int o[4] = {ro[g].x, ro[g].y, ro[g].z, ro[g].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float* __restrict__ src = o[k] >= 0 ? row + o[k] : v_prev + ~o[k];
+                    x[g][k] = *src;
+                }
+            }
+#pragma unroll
+        for (int g = 0; g < kCatGroups; ++g)
+            if (base + g * 1024 < D) {
+                const int64_t at = (int64_t)r * D + base + g * 1024;
+                if (OUTDT == 0) {
+                    *(float4*)((float*)img + at) = make_float4(x[g][0], x[g][1], x[g][2], x[g][3]);
+                } else {
+                    ushort4 h;
+                    h.x = f32_to_bf16(x[g][0]); h.y = f32_to_bf16(x[g][1]);
+                    h.z = f32_to_bf16(x[g][2]); h.w = f32_to_bf16(x[g][3]);
+                    *(ushort4*)((unsigned short*)img + at) = h;
+                }
+            }
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (e0 + k < D) {
-                const int o = role[e0 + k];
-                const float xv = o >= 0 ? row[o] : v_prev[~o];
-                if (OUTDT == 0) ((float*)img)[(int64_t)r * D + e0 + k] = xv;
-                else ((unsigned short*)img)[(int64_t)r * D + e0 + k] = f32_to_bf16(xv);
+        for (int g = 0; g < kCatGroups; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = base + g * 1024 + k;
+                if (e < D) {
+                    const int o = role[e];
+                    const float xv = o >= 0 ? row[o] : v_prev[~o];
+                    if (OUTDT == 0) ((float*)img)[(int64_t)r * D + e] = xv;
+                    else ((unsigned short*)img)[(int64_t)r * D + e] = f32_to_bf16(xv);
+                }
             }
-        }
     }
 }
 
@@ -394,7 +517,7 @@ int fbsmi_em_concat(const fbsmi_em_mask* mask, const float* us, const int32_t* A
     if (n == 0) return FBSMI_OK;
     FBSMI_NEED(us && img && (mask->dv == 0 || v_prev), "em_concat: null pointer");
     const int32_t D = mask->du + mask->dv;
-    const int32_t chunks = (D + 1023) / 1024;
+    const int32_t chunks = (D + 1024 * kCatGroups - 1) / (1024 * kCatGroups);
     FBSMI_NEED(n * chunks < (int64_t)1 << 31, "em_concat: too many rows");
     const bool vec = D % 4 == 0 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)mask->role & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
@@ -416,6 +539,7 @@ int fbsmi_em_finish(const fbsmi_em_mask* mask, const float* us, const int32_t* A
                    (mode == 0 || mode == 1), "em_finish: bad arguments");
     if (n == 0 || (!us_new && !lw)) return FBSMI_OK;
     FBSMI_NEED(net && n < ((int64_t)1 << 31), "em_finish: null network output or too many rows");
+    FBSMI_NEED(mask->du + mask->dv >= 4, "em_finish: images of fewer than 4 floats are not supported");
     FBSMI_NEED(!us_new || (us && us_new != us), "em_finish: the proposal needs us, and us_new must not alias it");
     FBSMI_NEED(!lw || mask->dv == 0 || (v && v_prev), "em_finish: the weights need v and v_prev");
     FBSMI_NEED(pin_row < 0 || (pin_row < n && pin_value), "em_finish: bad pin");
@@ -456,6 +580,7 @@ int fbsmi_em_transition_logpdf(const fbsmi_em_mask* mask, const float* us, const
                "em_transition_logpdf: bad arguments");
     if (n == 0) return FBSMI_OK;
     FBSMI_NEED(us && net && u && lw && n < ((int64_t)1 << 31), "em_transition_logpdf: null pointer");
+    FBSMI_NEED(mask->du + mask->dv >= 4, "em_transition_logpdf: images of fewer than 4 floats are not supported");
     FBSMI_NEED(((uintptr_t)mask->u_off & 15) == 0, "em_transition_logpdf: the mask tables must be 16-byte aligned");
     EmArgs a = {};
     a.us = us; a.net = net; a.v = u; a.lw = lw; a.u_off = mask->u_off; a.v_off = mask->v_off;

@@ -78,7 +78,11 @@ __global__ void k_math_map(int op, const float* x, const float* y, int64_t n, fl
             case 4: r = fbsmi_sqrtf(v); break;
             case 5: r = v / y[i]; break;
             case 6: r = fbsmi_bits_to_normal(fbsmi_f2u(v)); break;  // the definition
-            default: r = normal_from_bits(fbsmi_f2u(v)); break;     // the form the kernels use (fbsmi_device.h)
+            case 7: r = normal_from_bits(fbsmi_f2u(v)); break;     // the form the kernels use (fbsmi_device.h)
+            default: {                                               // x / y the way the log-density kernels divide
+                const float b = y[i];
+                r = (div_by_in_range(v) && div_by_in_range(b)) ? div_by(v, b, 1.0f / b) : v / b;
+            } break;
         }
         out[i] = r;
     }
@@ -624,7 +628,7 @@ int fbsmi_randint(uint32_t k0, uint32_t k1, int64_t n, int32_t lo, int32_t hi, i
 }
 
 int fbsmi_math_map(int op, const float* x, const float* y, int64_t n, float* out, void* stream) {
-    if (n < 0 || op < 0 || op > 7 || (n > 0 && (!x || !out)) || (op == 5 && !y))
+    if (n < 0 || op < 0 || op > 8 || (n > 0 && (!x || !out)) || ((op == 5 || op == 8) && !y))
         return fail(FBSMI_ERR_ARG, "math_map: bad arguments");
     if (n == 0) return FBSMI_OK;
     k_math_map<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(op, x, y, n, out);

@@ -161,7 +161,7 @@ def choice(key, a, shape=(), p=None, axis: int = 0):
 # ------------------------------------------------------------------------------------------------
 # numeric-specification probes
 # ------------------------------------------------------------------------------------------------
-_MATH_OPS = {"exp": 0, "log": 1, "log1p": 2, "erfinv": 3, "sqrt": 4, "div": 5, "bits_to_normal": 6, "bits_to_normal_kernel": 7}
+_MATH_OPS = {"exp": 0, "log": 1, "log1p": 2, "erfinv": 3, "sqrt": 4, "div": 5, "bits_to_normal": 6, "bits_to_normal_kernel": 7, "div_kernel": 8}
 
 
 def math_map(op: str, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:

@@ -53,7 +53,8 @@ int fbsmi_random_range(int mode, uint32_t k0, uint32_t k1, int64_t n_total, int6
 
 /* ---- numeric specification probes (include/fbsmi_math.h evaluated on the device) ------------
  * op: 0 exp, 1 log, 2 log1p, 3 erfinv, 4 sqrt, 5 x/y, 6 bits->normal (x reinterpreted as uint32), 7 the same
- * through the kernels' branch-free device form (must equal 6 bit for bit on every input). */
+ * through the kernels' branch-free device form (must equal 6 bit for bit on every input), 8 x/y through the kernels'
+ * reciprocal-and-correction form (must equal 5 bit for bit). */
 int fbsmi_math_map(int op, const float* x, const float* y, int64_t n, float* out, void* stream);
 
 /* ---- tree reductions / scans -------------------------------------------------------------- */

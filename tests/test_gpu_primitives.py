@@ -205,3 +205,23 @@ def test_kernel_normal_equals_the_definition_on_all_2_23_arguments(oracle, dev):
     got = b.cpu().numpy()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert np.isfinite(got).all() and abs(float(got.mean())) < 1e-3 and abs(float(got.std()) - 1.0) < 1e-3
+
+
+def test_kernel_division_equals_ieee_division(dev):
+    """div_by (fbs_amd/csrc/fbsmi_device.h): the reciprocal-and-two-corrections quotient the log-density kernels use for
+    (v - mean)^2 / sd^2, against float32 `/` on 2^26 operand pairs spread over the exponents it is used for (and, outside
+    them, the fall-back to `/`)."""
+    from fbs_amd import ops
+    g = torch.Generator(device=dev).manual_seed(1)
+    n = 1 << 26
+    mant = lambda: torch.rand(n, device=dev, generator=g) + 1.0
+    ea = torch.randint(-70, 71, (n,), device=dev, generator=g).float()
+    eb = torch.randint(-40, 11, (n,), device=dev, generator=g).float()
+    a = mant() * torch.exp2(ea)
+    b = mant() * torch.exp2(eb)
+    a[:1000] = 0.0
+    a[1000:2000] = torch.finfo(torch.float32).tiny * 3
+    want = ops.math_map("div", a, b)
+    got = ops.math_map("div_kernel", a, b)
+    assert torch.equal(want.view(torch.int32), got.view(torch.int32))
+    assert torch.equal(want, a / b)

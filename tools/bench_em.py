@@ -25,6 +25,9 @@ SHAPES = {
 }
 
 
+ONLY = set()
+
+
 def time_kernel(fn, nsets, iters):
     """Average duration in microseconds of fn(set) over iters * nsets back-to-back launches between ONE hipEvent pair
     (host launch latency overlaps the previous kernel), cycling through `nsets` disjoint buffer sets so that a launch
@@ -91,6 +94,8 @@ def run(name, net_dtype, sliced, iters, nsets):
                               ("finish_proposal_only", prop_only, n * (8 * em.du + s * em.du)),
                               ("finish_weights_only", lw_only, n * (4 + s * em.dv)),
                               ("concat", concat, n * (4 * em.du + s * em.D))):
+        if ONLY and label not in ONLY:
+            continue
         us_ = time_kernel(fn, nsets, iters)
         out[label] = {"us": round(us_, 2), "algorithmic_bytes": nbytes, "GBps": round(nbytes / us_ / 1e3, 1),
                       "frac_of_8TBps": round(nbytes / us_ / 1e3 / 8000.0, 4)}
@@ -104,7 +109,9 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="f32,bf16")
     ap.add_argument("--sliced", default="0,1")
     ap.add_argument("--sets", type=int, default=0, help="buffer sets to cycle through (0: enough for > 512 MB)")
+    ap.add_argument("--only", default="", help="comma list of kernels to time (finish, finish_proposal_only, ...)")
     a = ap.parse_args()
+    ONLY.update(x for x in a.only.split(",") if x)
     _lib.build()
     for nm in a.shapes.split(","):
         for dt in a.dtype.split(","):

@@ -1,16 +1,23 @@
 #!/bin/bash
-# Diagnostic builds of libfbsmi with other compile-time tile parameters, for A/B timing on the GPU box
-# (FBSMI_LIB=tools/variants/<name>.so python tools/bench_em.py ...).  Usage: tools/build_variants.sh "B W" ["B W" ...]
-# B = FBSMI_EM_SEGBATCH, W = FBSMI_EM_WAVES (fbs_amd/csrc/fbsmi_em.hip).
+# Diagnostic builds of libfbsmi with other compile-time parameters of fbs_amd/csrc/fbsmi_em.hip, for A/B timing on ONE
+# GPU box (devices differ by ~10 %: never compare timings from two gpurun calls):
+#   FBSMI_LIB=tools/variants/<name>.so python tools/bench_em.py ...
+# Usage: tools/build_variants.sh name1 "-DFLAG=..." name2 "-D..." ...   (pairs of name and extra hipcc flags)
 set -e
 cd "$(dirname "$0")/.."
-mkdir -p tools/variants
-for cfg in "$@"; do
-  set -- $cfg
-  out=tools/variants/em_b$1_w$2.so
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -Wno-pass-failed \
-    -DFBSMI_EM_SEGBATCH=$1 -DFBSMI_EM_WAVES=$2 -o $out fbs_amd/csrc/fbsmi_prims.hip fbs_amd/csrc/fbsmi_lg.hip \
-    fbs_amd/csrc/fbsmi_sde.hip fbs_amd/csrc/fbsmi_nn.hip fbs_amd/csrc/fbsmi_em.hip &
+mkdir -p tools/variants/obj
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value -Wno-pass-failed"
+for f in fbsmi_prims fbsmi_lg fbsmi_sde fbsmi_nn; do
+  if [ ! -f tools/variants/obj/$f.o ] || [ fbs_amd/csrc/$f.hip -nt tools/variants/obj/$f.o ] || [ fbs_amd/csrc/fbsmi_device.h -nt tools/variants/obj/$f.o ]; then
+    /opt/rocm/bin/hipcc $FLAGS -c -o tools/variants/obj/$f.o fbs_amd/csrc/$f.hip &
+  fi
 done
 wait
-ls -la tools/variants
+while [ $# -ge 2 ]; do
+  name=$1; extra=$2; shift 2
+  ( /opt/rocm/bin/hipcc $FLAGS $extra -c -o tools/variants/obj/em_$name.o fbs_amd/csrc/fbsmi_em.hip && \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/variants/$name.so tools/variants/obj/em_$name.o \
+      tools/variants/obj/fbsmi_prims.o tools/variants/obj/fbsmi_lg.o tools/variants/obj/fbsmi_sde.o tools/variants/obj/fbsmi_nn.o ) &
+done
+wait
+ls tools/variants/*.so
