@@ -14,7 +14,15 @@ launch advances all chains of the batch, exactly as the reference's single XLA p
 single-chain rate is measured too and reported in `single_chain`.
 
 Multi-GPU (--gpus N under torch.distributed.run): every GPU runs its own batch of chains -- the
-reference's own parallel axes (nchains, --id replicas) -- no data-path collective, weak scaling.
+reference's own parallel axes (nchains, --id replicas) -- no data-path collective, weak scaling: that is `value`.
+The SAME run also times one particle ensemble SHARDED over the N ranks (`sharded_c5`: BASELINE config 5's
+16 384 particles, fbs_amd/sharded.py: RCCL all_gather of the log-weights + ancestor rows by all_gather or by
+all_to_all), strong scaling, so a 1 -> 8 GPU series carries both axes.
+
+Extra objects of the line (all measured in this process unless they say otherwise): `single_chain`, `batch_scan`,
+`spill` (a working set beyond the Infinity Cache), `gp100` (the reference's d = 100 toy), `c3` / `c4_shard` /
+`c5_shard` (the image configurations per SMC step, network and sampler time apart), `em_finish` (roofline of the
+fused score-network step kernel at config 5's per-GPU shape), `sharded_c5`.
 """
 import argparse
 import json
@@ -90,6 +98,135 @@ def gp100_leg(dev):
                     "and latency-bound"}
 
 
+def image_legs(dev, nsteps):
+    """Configs 3-5 in shape (fbs_amd/image_configs.py: synthetic image, random-init UNet dim 64, bf16): one
+    gibbs_kernel sweep of `nsteps` of the configuration's steps on this GPU's share of the particles, network time
+    (torch events around every network call) and sampler time (everything else) apart."""
+    from fbs_amd import image_configs, ops
+    out = {}
+    for name, label in (("c3", "c3"), ("c4", "c4_shard"), ("c5", "c5_shard")):
+        c = image_configs.make(name, dev, dtype="bf16", nsteps=nsteps)
+        n = c.shard_rows
+        image_configs.gibbs_sweep(c, ops.PRNGKey(3), n)
+        torch.cuda.synchronize(dev)
+        image_configs.network_ms(c)
+        c.sb.profile = {}
+        t0 = time.perf_counter()
+        image_configs.gibbs_sweep(c, ops.PRNGKey(4), n)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        net_ms = image_configs.network_ms(c)
+        pr = c.sb.profile
+        ev = lambda a, b: sum(x.elapsed_time(y) for x, y in zip(pr[a], pr[b])) / max(1, len(pr[a])) * 1e3
+        full = image_configs.CONFIGS[name]
+        out[label] = {"workload": f"{full['task']} on {full['image']}, UNet dim 64 random init bf16, {n} particles on this GPU "
+                                  f"(+1: explicit_final; ensemble {full['nparticles']} over {full['ngpus']} GPU(s)), "
+                                  f"{nsteps} of the configuration's {full['nsteps']} steps timed",
+                      "ms_per_step": dt / nsteps * 1e3, "network_ms_per_step": net_ms / nsteps,
+                      "sampler_ms_per_step": (dt * 1e3 - net_ms) / nsteps, "particle_steps_per_s": n * nsteps / dt,
+                      "full_sweep_s_extrapolated": dt / nsteps * full["nsteps"],
+                      "concat_kernel_us_with_event_overhead": ev("concat0", "concat1"),
+                      "finish_kernel_us_with_event_overhead": ev("finish0", "finish1")}
+        del c
+        torch.cuda.empty_cache()
+    return out
+
+
+def em_finish_roofline(dev):
+    """The fused score-network step kernel (fbsmi_em_finish: ancestor gather + unpack + Euler-Maruyama with in-kernel
+    normal + pin + row-summed log-density) at config 5's per-GPU shape (2048 rows of du = 3072, dv = 9216), float32
+    network output: back-to-back launches between one hipEvent pair on the launch stream, cycling through buffer sets
+    larger than the Infinity Cache so that every launch streams from HBM.  Algorithmic bytes per particle: 8 du + 8
+    (Euler sub-sweep) + 4 (du + dv) (the network output it consumes)."""
+    from fbs_amd import _lib, ops
+    from fbs_amd.images import ImageRestore
+    from fbs_amd.score import EMMask
+    n, shape = 2048, (64, 64, 3)
+    ds = ImageRestore("inpaint-32", shape, device=dev)
+    em = EMMask(ds.gen_mask(ops.PRNGKey(1)), 3, dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    nsets = 4
+    sets = [dict(us=torch.randn((n, em.du), device=dev, generator=g), net=torch.randn((n, em.D), device=dev, generator=g),
+                 A=torch.randint(0, n, (n,), device=dev, generator=g, dtype=torch.int32),
+                 us_new=torch.empty((n, em.du), device=dev), lw=torch.empty(n, device=dev),
+                 img=torch.empty((n, em.D), device=dev)) for _ in range(nsets)]
+    v, vp = torch.randn(em.dv, device=dev, generator=g), torch.randn(em.dv, device=dev, generator=g)
+    pin = torch.randn(em.du, device=dev, generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def finish(b):
+        _lib.call("fbsmi_em_finish", em.ref, b["us"].data_ptr(), b["A"].data_ptr(), b["net"].data_ptr(), None, 0, 0, 1.3,
+                  2.6, 0.002, 0.0721, v.data_ptr(), vp.data_ptr(), 1, 2, n, 0, n, 5, pin.data_ptr(), b["us_new"].data_ptr(),
+                  b["lw"].data_ptr(), st)
+
+    def concat(b):
+        _lib.call("fbsmi_em_concat", em.ref, b["us"].data_ptr(), b["A"].data_ptr(), vp.data_ptr(), n, 0, b["img"].data_ptr(), st)
+
+    def timed(fn, iters=10):
+        for b in sets:
+            fn(b)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            for b in sets:
+                fn(b)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / (iters * nsets) * 1e3
+
+    fus, cus = timed(finish), timed(concat)
+    fbytes, cbytes = n * (8 * em.du + 8 + 4 * em.D), n * (4 * em.du + 4 * em.D)
+    return {"bound": "hbm", "kernel": "k_em_finish (fbs_amd/csrc/fbsmi_em.hip)", "shape": "config 5 per-GPU share: 2048 rows, "
+            "du=3072, dv=9216, float32 network output, cold (4 buffer sets, 600 MB)", "avg_launch_us": fus,
+            "bytes_per_launch": fbytes, "achieved": fbytes / fus / 1e3, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": fbytes / fus / 1e3 / PEAK_HBM_GBS, "traffic": None,
+            "concat_kernel": {"avg_launch_us": cus, "bytes_per_launch": cbytes, "achieved": cbytes / cus / 1e3,
+                              "frac": cbytes / cus / 1e3 / PEAK_HBM_GBS},
+            "note": "the same box's torch copy_ of 100 MB cold buffers moves 5.1 TB/s = 0.64 of the 8 TB/s peak; the finish kernel "
+                    "also issues ~140 vector instructions per unobserved element (Threefry + erf_inv): see DESIGN.md section 5"}
+
+
+def sharded_leg(dev, dist, world, rank, nsteps):
+    """BASELINE config 5 as ONE ensemble of 16 384 particles sharded over the ranks (fbs_amd/sharded.py): per SMC step an
+    all_gather of the log-weights, the ancestor rows by all_gather or all_to_all over RCCL, the network and the fused
+    step kernels on the local rows.  Strong scaling: the ensemble is fixed, the per-rank share is 16384 / world."""
+    from fbs_amd import image_configs, ops, sharded
+    c = image_configs.make("c5", dev, dtype="bf16", nsteps=nsteps)
+    N = c.cfg["nparticles"]
+    sb = c.sb
+    bs = np.zeros(nsteps + 1, np.int32)
+    res = {}
+    for exchange in ("all_gather", "all_to_all"):
+        sh = sharded.ParticleShards(N + 1, dist=dist, exchange=exchange)
+        run = lambda key: sharded.gibbs_kernel(key, c.x0, c.y0, None, bs, c.ts, sb.fwd_sampler, c.sde, sb.unpack, N,
+                                               sb.transition_sampler, sb.transition_logpdf, sb.likelihood_logpdf, sh,
+                                               explicit_final=True, mask_=c.mask)
+        run(ops.PRNGKey(5))
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        image_configs.network_ms(c)
+        sh.bytes_moved = 0
+        t0 = time.perf_counter()
+        out = run(ops.PRNGKey(6))
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
+        net_ms = image_configs.network_ms(c)
+        res[exchange] = {"value": float(N) * nsteps / dt, "unit": "particle-steps/s", "ms_per_step": dt / nsteps * 1e3,
+                         "network_ms_per_step_rank0": net_ms / nsteps, "rows_per_rank": sh.n,
+                         "ancestor_exchange_bytes_received_per_step_rank0": sh.bytes_moved / nsteps,
+                         "logweight_all_gather_bytes_per_step": 4 * (sh.world - 1) * sh.n,
+                         "x0_checksum": float(out[0].double().sum().item())}
+    res["workload"] = (f"CelebA-64 inpaint-32 (config 5), ONE ensemble of {N} (+1) particles over {world} rank(s), UNet dim 64 "
+                       f"random init bf16, gibbs_kernel eb=ef=True, {nsteps} of 1000 steps timed; strong scaling")
+    res["scaling"] = "strong"
+    res["n_gpus"] = world
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,7 +241,17 @@ def main():
     ap.add_argument("--no-gp100", action="store_true", help="skip the d = 100 Gaussian-process toy leg (`gp100`)")
     ap.add_argument("--batch-scan", type=str, default="16,32",
                     help="extra chain-batch sizes timed (untimed region) and reported in `batch_scan`; '' to skip")
+    ap.add_argument("--image-steps", type=int, default=6, help="SMC steps timed per image configuration (0: skip the legs)")
+    ap.add_argument("--sharded-steps", type=int, default=2, help="SMC steps of the sharded config-5 ensemble (0: skip)")
+    ap.add_argument("--no-spill", action="store_true", help="skip the beyond-the-Infinity-Cache leg (`spill`)")
     args = ap.parse_args()
+
+    # native pieces are built before anything touches the GPU (hipcc / gcc children must not inherit a profiler's preload)
+    from fbs_amd import _lib as _fbsmi_lib
+    _fbsmi_lib.build()
+    if not args.no_cpu_baseline:
+        import oracle as _oracle_build
+        _oracle_build.build()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,26 +328,40 @@ def main():
         net = {k: max(v - c_ev, 1e-3) for k, v in raw.items()}
         prop_us = net["prop"]
         achieved = prop_bytes / (prop_us * 1e-6) / 1e9
-        traffic, valu_insts = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("k_lg_prop_bytes_per_launch")
-                valu_insts = tj.get("k_lg_prop_valu_insts_per_launch")
-            except Exception:
-                traffic = None
-        # VALU issue roof: one wave64 instruction per CU per clock (4 SIMDs x 1 per 4 clocks), 256 CUs at ~2.4 GHz;
-        # f64 instructions (the exp of the numeric spec) take two slots, so this is a lower bound on the occupancy
-        valu_frac = (valu_insts / (256.0 * 2.4e3 * prop_us)) if (valu_insts and C == 4) else None
+        # PMC figures cannot be collected inside this process: they come from a rocprofv3 --pmc run of this same command
+        # whose summary is committed under profiles/ (newest round first), and are reported ONLY under `from_profile_file`,
+        # and only when that file describes the kernel and workload this run launched.
+        prof = None
+        kname = "k_lg_prop1t" if "cdf" not in kern else "k_lg_prop"
+        for rr in range(9, 0, -1):
+            tpath = os.path.join(ROOT, "profiles", f"r{rr:02d}_pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                except Exception:
+                    break
+                wl = tj.get("workload", {})
+                if tj.get("kernel", "").startswith(kname) and wl == {"nparticles": N, "nsteps": T, "nchains": C}:
+                    insts = tj.get("valu_insts_per_launch")
+                    prof = {"file": os.path.relpath(tpath, ROOT), "kernel": tj.get("kernel"), "workload": wl,
+                            "hbm_bytes_per_launch": tj.get("bytes_per_launch"),
+                            "valu_insts_per_launch": insts,
+                            "valu_issue_frac": (insts * float(tj.get("cycles_per_valu_inst", 2.7)) / 4.0 /
+                                                (256.0 * 2.4e3 * prop_us)) if insts else None,
+                            "note": "measured by rocprofv3 in a separate run of this command, not in this process; "
+                                    "valu_issue_frac = instructions x measured issue cycles / (1024 SIMDs x 2.4 GHz x launch time)"}
+                break
         roofline = {"bound": "hbm", "kernel": "k_lg_prop1t (tree-walking searches + resample + gather + Euler-Maruyama + log-weight)"
                     if "cdf" not in kern else "k_lg_prop (resample + gather + Euler-Maruyama + log-weight)",
                     "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                    "traffic": traffic, "bytes_per_launch": prop_bytes, "avg_launch_us": prop_us,
+                    "traffic": None, "from_profile_file": prof,
+                    "limiter": "vector-instruction issue and dependent round trips (the per-step working set is cache resident): "
+                               "the HBM fraction is reported because SURVEY 8(d) assigns this path the HBM roof, not because "
+                               "the kernel is near it",
+                    "bytes_per_launch": prop_bytes, "avg_launch_us": prop_us,
                     "timing": "hipEvent pairs around each launch on the launch stream, net of the event overhead "
                               "calibrated against the graph-timed step (see bench.py)",
                     "event_overhead_us": c_ev, "raw_event_us": raw, "kernels_us": net,
-                    "valu_issue_frac": valu_frac,
                     "whole_sweep_GBps": bpp["step"] * float(N) * T * C / (ms_per_step * 1e-3) / 1e9,
                     "whole_step_frac": bpp["step"] * float(N) * T * C / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
                     "launches_per_step": len(kern),
@@ -233,9 +394,32 @@ def main():
                 scan.append({"nchains": cb, "value": float(N) * T * cb / bdt, "ms_per_sweep": bdt * 1e3,
                              "whole_sweep_GBps": bpp["step"] * float(N) * T * cb / bdt / 1e9})
                 del swb
+        spill = None
+        if world == 1 and not args.no_spill and not args.no_single_chain:
+            # a working set beyond the 256 MiB Infinity Cache: 4 chains x 2^22 particles, ~100 MB of per-step arrays each
+            Ns, Ts, Cs = 1 << 22, 20, 4
+            brs = fbs_amd.LinearGaussianBridge(m0, cov0, StationaryConstLinearSDE(a=-0.5, b=1.0),
+                                               np.linspace(0.0, T_END, Ts + 1), du=1, device=dev)
+            sws = brs.sweep_handle(Ns, True, False, nchains=Cs)
+            ks, xs_, bs_, _ = sws.chain(key, np.zeros((Cs, 1), np.float32), y0, np.zeros((Cs, Ts + 1), np.int32), 1, keep=False)
+            torch.cuda.synchronize(dev)
+            q0 = time.perf_counter()
+            sws.chain(ks, xs_, y0, bs_, 3, keep=False)
+            torch.cuda.synchronize(dev)
+            qdt = (time.perf_counter() - q0) / 3
+            spill = {"nparticles": Ns, "nsteps": Ts, "nchains": Cs, "value": float(Ns) * Ts * Cs / qdt,
+                     "unit": "particle-steps/s", "ms_per_sweep": qdt * 1e3,
+                     "whole_sweep_GBps": bpp["step"] * float(Ns) * Ts * Cs / qdt / 1e9,
+                     "whole_step_frac_of_hbm_peak": bpp["step"] * float(Ns) * Ts * Cs / qdt / 1e9 / PEAK_HBM_GBS,
+                     "note": "same model and kernels as the headline, per-step arrays ~400 MB: beyond the Infinity Cache"}
+            del sws, brs
         gp100 = None
         if world == 1 and not args.no_gp100 and not args.no_single_chain:
             gp100 = gp100_leg(dev)
+        images, emroof = None, None
+        if world == 1 and args.image_steps > 0 and not args.no_single_chain:
+            emroof = em_finish_roofline(dev)
+            images = image_legs(dev, args.image_steps)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             import oracle as O
@@ -264,8 +448,20 @@ def main():
                           "(reference driver default nchains=4, vmapped)",
                           "nparticles": N, "nsteps": T, "nchains": C, "du": br.du, "dv": br.dv,
                           "parallelism": f"{world} GPU(s) x {C} independent chain(s) each, no collective"},
-               "roofline": roofline, "cpu_baseline": cpu, "single_chain": single, "batch_scan": scan, "gp100": gp100,
+               "roofline": roofline, "cpu_baseline": cpu,
+               "value_single_chain": single["value"] if single else None, "single_chain": single, "batch_scan": scan,
+               "spill": spill, "gp100": gp100, "em_finish": emroof,
                "x0_mean_of_timed_sweeps": float(x0s.float().mean().item())}
+        if images:
+            out.update(images)
+    # every rank takes part in the sharded ensemble (collectives); rank 0 reports
+    shard = None
+    if args.sharded_steps > 0 and not args.no_single_chain:
+        del sweep
+        torch.cuda.empty_cache()
+        shard = sharded_leg(dev, dist, world, rank, args.sharded_steps)
+    if rank == 0:
+        out["sharded_c5"] = shard
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

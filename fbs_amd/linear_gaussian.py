@@ -99,9 +99,16 @@ class LinearGaussianBridge:
 
     # -- helpers ---------------------------------------------------------------------------------
     def step_of(self, t_prev) -> int:
+        """Index of the step that leaves time t_prev; the closures are tabulated on the bridge's own grid."""
         t = float(t_prev)
         k = int(np.argmin(np.abs(self.ts_np[:-1] - t)))
+        if abs(self.ts_np[k] - t) > 1e-6 * max(1.0, abs(self.ts_np[-1])):
+            raise ValueError(f"t_prev = {t} is not a point of this bridge's time grid (nearest: {self.ts_np[k]})")
         return k
+
+    def same_grid(self, ts) -> bool:
+        ts = np.asarray(ts.detach().cpu() if isinstance(ts, torch.Tensor) else ts, np.float64).reshape(-1)
+        return ts.shape == self.ts_np.shape and bool(np.allclose(ts, self.ts_np, rtol=0.0, atol=1e-9 * max(1.0, abs(self.ts_np[-1]))))
 
     def _t(self, x, shape=None) -> torch.Tensor:
         if not isinstance(x, torch.Tensor):

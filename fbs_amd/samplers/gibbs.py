@@ -67,17 +67,24 @@ def _lg_model_of(*closures):
     return models[0] if all(m is models[0] for m in models) else None
 
 
+def _same_sde(a, b) -> bool:
+    """The same SDE object, or one of the same class with the same coefficients."""
+    return a is b or (type(a) is type(b) and vars(a) == vars(b))
+
+
 def gibbs_kernel(key, x0, y0, us_star, bs_star, ts, fwd_sampler, sde, unpack, nparticles, transition_sampler,
                  transition_logpdf, likelihood_logpdf, marg_y: bool = False, explicit_backward: bool = True,
                  explicit_final: bool = False, **kwargs):
     """Gibbs kernel of the forward-backward conditional sampler (gibbs.py:68-168).
 
     Returns (x0, us_star, bs_star, acc) like the reference."""
-    model = _lg_model_of(fwd_sampler, transition_sampler, likelihood_logpdf)
-    nsteps = (ts.shape[0] if hasattr(ts, "shape") else len(ts)) - 1
-    if model is not None and not marg_y and not kwargs and model.T == nsteps and \
+    # the fused engine runs the model's OWN grid, SDE and split: take it only when the caller passed exactly those
+    model = _lg_model_of(fwd_sampler, transition_sampler, likelihood_logpdf, unpack)
+    if model is not None and not marg_y and not kwargs and _same_sde(sde, model.sde) and model.same_grid(ts) and \
+            (explicit_backward or _lg_model_of(transition_logpdf) is model) and \
             model.fused_sweep_supported(nparticles, explicit_final):
-        return model.gibbs_kernel(key, x0, y0, bs_star, nparticles, explicit_backward, explicit_final)
+        with torch.cuda.device(model.device):
+            return model.gibbs_kernel(key, x0, y0, bs_star, nparticles, explicit_backward, explicit_final)
 
     key_fwd, key_csmc, key_bridge = ops.split(key, 3)                               # :126
     path_xy = fwd_sampler(key_fwd, x0, y0, **kwargs)                                # :127

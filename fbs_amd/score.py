@@ -77,6 +77,7 @@ class ScoreBridge:
         self._masks = {}
         self._buf = {}
         self.profile = None                                  # set to a dict to collect torch events per phase
+        self.capture = None                                  # set to a dict: operands and results of the LAST fused step
 
     # -- plumbing -----------------------------------------------------------------------------------
     def _em_mask(self, mask_) -> EMMask:
@@ -164,6 +165,10 @@ class ScoreBridge:
         A32 = A.to(torch.int32).contiguous() if A is not None else None
         net = self._network(us2, A32, v_prev, t_prev, em)
         us_new, lw = self._finish(em, us2, A32, net, t_prev, v, v_prev, key_, row_slice, pin, True, want_lw)
+        if self.capture is not None:                         # parity tests replay this step through the oracle
+            self.capture.update(us=us2, A=A32, net=net, img=self._buf["img"], v=v, v_prev=v_prev, t_prev=float(t_prev),
+                                key=np.asarray(key_, np.uint32).copy(), pin=pin, row_slice=row_slice, us_new=us_new,
+                                lw=lw, coef=self._coef(t_prev), em=em)
         return us_new.reshape((us_new.shape[0],) + tuple(self.dataset.unobs_shape)), lw
 
     def fused_weight_then_propose(self, us, v, v_prev, t_prev, key_, mask_, resample):

@@ -1,28 +1,35 @@
 """One particle ensemble sharded over the ranks of a process group.
 
-Rank g owns the particle slots [g*n, (g+1)*n), n = N / world.  What is expensive -- propagating
-and weighting particles through the model closures (the score network for images) -- runs on the
-local slots only.  Per SMC step there are exactly two exchanges:
+The R rows of the ensemble (R = nparticles, or nparticles + 1 with explicit_final: gibbs.py:133-134) are cut
+into `world` contiguous shards of n = ceil(R / world) slots; rank g owns rows [g n, min((g + 1) n, R)) -- only
+the last shard can be short, its missing slots are padding that no weight, ancestor or draw ever refers to.
+What is expensive -- propagating and weighting particles through the model closures (the score network for
+images) -- runs on the local rows only.  Per SMC step there are exactly two exchanges:
 
-1. ``all_gather`` of the N unnormalised log-weights (4N bytes).  Every rank then holds the full
-   weight vector and computes the normalising constant / ESS, the resampling CDF and the ancestor
-   indices of ALL slots redundantly with the single-GPU kernels.  That costs O(N) scalar work per
-   rank, removes every further scalar collective, and -- because the canonical summation tree does
-   not depend on how the slots are partitioned -- makes the sharded run produce bit-identical
-   ancestors, weights and particles to the unsharded one.
-2. ``all_to_all`` of ancestor rows: slot m needs row A[m], which may live on another rank.  Since A
-   is known everywhere, every rank derives the send/receive plan locally (no count exchange).  The
-   conditional killing resampler leaves survivors in place up to one global rotation
-   (resamplings.py:85), so the traffic is mostly a contiguous shift between neighbours.
+1. ``all_gather`` of the R unnormalised log-weights (4 n bytes per rank).  Every rank then holds the full weight
+   vector and computes the normalising constant / ESS, the resampling CDF and the ancestor indices of ALL rows
+   redundantly with the single-GPU kernels.  That costs O(R) scalar work per rank, removes every further scalar
+   collective, and -- because the canonical summation tree does not depend on how the rows are partitioned --
+   makes the sharded run produce bit-identical ancestors, weights and particles to the unsharded one.
+2. the ancestor rows: slot m needs row A[m], which may live on another rank.  Two forms:
+   * ``exchange="all_gather"`` (default): one ``all_gather`` of the particle array; the ancestor gather itself is
+     then folded into the kernel that builds the network input (fbsmi_em_concat reads us_full[A[m]]).  No plan, no
+     host synchronisation, one collective of fixed shape; it moves n du floats to every rank whatever the
+     ancestors are (config 5: 25 MB per rank and step, ~0.1 ms on xGMI against a 170 ms network evaluation).
+   * ``exchange="all_to_all"``: the all-to-all of the north-star design.  A is replicated, so every rank derives
+     who sends which rows to whom ON THE DEVICE (no count exchange); only the 2 x world split sizes come to the
+     host (one small copy per step -- ``all_to_all_single`` takes Python split lists), and only rows whose
+     ancestor lives elsewhere travel.  The conditional killing resampler leaves survivors in place up to one global
+     rotation (resamplings.py:85), so the traffic is mostly a contiguous shift between neighbours.
 
-After the last step the forced-move index is drawn from the replicated weights and the selected
-particle is broadcast from its owner.  With NCCL (= RCCL on ROCm) the two exchanges are
-``ncclAllGather`` / ``ncclAllToAllv`` over xGMI; the same code runs over gloo (CPU tensors) in the
-tests.
+After the last step the forced-move index is drawn from the replicated weights and the selected particle is
+broadcast from its owner.  Per-row noise is drawn as a slice of the global draw (``row_slice = (offset, count,
+total)``), so every rank's rows equal the unsharded sweep's.  With NCCL (= RCCL on ROCm) the exchanges are
+``ncclAllGather`` / ``ncclAllToAllv`` over xGMI; the same code runs over gloo (CPU tensors) in the tests.
 
-The local array operations come from a small ``backend`` namespace; the product default is the
-libfbsmi-backed GPU backend below (no CPU path), tests may inject another implementation of the same
-functions to exercise the exchange logic without a GPU.
+The local array operations come from a small ``backend`` namespace; the product default is the libfbsmi-backed
+GPU backend below (no CPU path); tests may inject another implementation of the same functions to exercise the
+exchange and slicing logic without a GPU.
 """
 from __future__ import annotations
 
@@ -38,76 +45,102 @@ def gpu_backend():
     from . import ops
     from .samplers.csmc.resamplings import killing
     from .samplers.gibbs import force_move
+    from .score import bridge_of
+
+    def fused_step(closures, us_src, A_local, v, v_prev, t_prev, key, pin, row_slice, kwargs):
+        """One network evaluation per step when the closures are a ScoreBridge's (fbs_amd/score.py), else None."""
+        sb = bridge_of(*closures) if set(kwargs) == {"mask_"} else None
+        if sb is None:
+            return None
+        return sb.fused_step(us_src, A_local, v, v_prev, t_prev, key, kwargs["mask_"], pin=pin, row_slice=row_slice)
+
     return SimpleNamespace(split=ops.split, normalise=ops.normalise, exp=lambda x: ops.math_map("exp", x),
                            take_rows=ops.take_rows, set_row=ops.set_row, cond_resampling=killing,
-                           force_move=force_move, randint=ops.randint)
+                           force_move=force_move, randint=ops.randint, normal=ops.normal, fused_step=fused_step)
 
 
 class ParticleShards:
-    """Slot ownership and the two exchanges."""
+    """Slot ownership and the exchanges."""
 
-    def __init__(self, n_total: int, group=None, dist=None):
+    def __init__(self, n_total: int, group=None, dist=None, exchange: str = "all_gather"):
         self.dist = dist
         if dist is not None and dist.is_initialized():
             self.world = dist.get_world_size(group)
             self.rank = dist.get_rank(group)
         else:
             self.world, self.rank = 1, 0
-        self.group = group
-        if n_total % self.world:
-            raise ValueError(f"the ensemble size {n_total} must be a multiple of the world size {self.world}")
-        self.N = int(n_total)
-        self.n = self.N // self.world
+        if exchange not in ("all_gather", "all_to_all"):
+            raise ValueError(f"unknown exchange {exchange}")
+        self.group, self.exchange = group, exchange
+        self.R = int(n_total)
+        self.n = -(-self.R // self.world)                      # slots per rank
         self.offset = self.rank * self.n
+        self.count = max(0, min(self.n, self.R - self.offset))  # rows this rank really owns
+        if self.R < self.world:
+            raise ValueError(f"an ensemble of {self.R} rows cannot be split over {self.world} ranks")
+        self.bytes_moved = 0                                   # payload this rank received in ancestor exchanges
+
+    # kept for callers of the round-1 interface
+    @property
+    def N(self):
+        return self.R
 
     @property
     def row_slice(self):
-        return (self.offset, self.n, self.N)
-
-    def owner(self, idx):
-        return idx // self.n
+        return (self.offset, self.count, self.R)
 
     def owns(self, slot: int) -> bool:
-        return self.offset <= int(slot) < self.offset + self.n
+        return self.offset <= int(slot) < self.offset + self.count
 
-    def all_gather_vec(self, x_local: torch.Tensor) -> torch.Tensor:
-        """Concatenate every rank's (n, ...) slice into the full (N, ...) array, on every rank."""
+    def _pad(self, x_local: torch.Tensor) -> torch.Tensor:
+        if x_local.shape[0] == self.n:
+            return x_local.contiguous()
+        pad = torch.zeros((self.n - x_local.shape[0],) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+        return torch.cat([x_local, pad], 0)
+
+    def all_gather_rows(self, x_local: torch.Tensor) -> torch.Tensor:
+        """Every rank's (count, ...) rows -> the full (R, ...) array, on every rank."""
         if self.world == 1:
             return x_local
-        x_local = x_local.contiguous()
-        full = torch.empty((self.N,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
-        self.dist.all_gather_into_tensor(full, x_local, group=self.group)
-        return full
+        x = self._pad(x_local)
+        full = torch.empty((self.world * self.n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        self.dist.all_gather_into_tensor(full, x, group=self.group)
+        return full[:self.R]                                    # shards are contiguous: only the tail is padding
+
+    all_gather_vec = all_gather_rows
 
     def exchange_plan(self, A_full: torch.Tensor):
-        """Who sends which rows to whom, derived locally from the replicated ancestor array.
+        """Who sends which rows to whom, derived from the replicated ancestor array on the device.
 
-        Returns (send_rows, send_splits, recv_splits, recv_positions): the local row numbers this
-        rank sends (grouped by destination rank, destination-slot order inside a group), the per-rank
-        counts, and for the rows it receives (grouped by source rank) the local slot each one fills."""
-        A = A_full.to(torch.int64).reshape(self.world, self.n)        # A[q] = requests of rank q
-        own = A // self.n
-        mine = own == self.rank                                        # (world, n): rows I must send to q
-        send_splits = mine.sum(dim=1).tolist()
-        send_rows = (A[mine] - self.offset)                            # row-major: grouped by q, slot order
-        my_req_owner = own[self.rank]                                  # (n,): owner of each row I need
-        order = torch.argsort(my_req_owner, stable=True)               # grouped by source rank, slot order
-        recv_splits = torch.bincount(my_req_owner, minlength=self.world).tolist()
-        return send_rows, send_splits, recv_splits, order
+        Returns (send_rows, splits (2, world) int64 on the device: row 0 = rows this rank sends to each rank, row 1 = rows
+        it receives from each rank, order): the local row numbers this rank sends (grouped by destination rank, destination
+        slot order inside a group) and, for the rows it receives (grouped by source rank), the local slot each one fills."""
+        A = A_full.to(torch.int64).reshape(-1)
+        slots = torch.arange(self.R, device=A.device)
+        dest = slots // self.n                                   # rank that needs row A[m] for its slot m
+        own = A // self.n                                        # rank that holds row A[m]
+        mine = own == self.rank
+        send_rows = A[mine] - self.offset                        # slot order = grouped by destination rank
+        send_splits = torch.bincount(dest[mine], minlength=self.world)
+        my_owner = own[self.offset:self.offset + self.count]
+        order = torch.argsort(my_owner, stable=True)             # grouped by source rank, slot order inside
+        recv_splits = torch.bincount(my_owner, minlength=self.world)
+        return send_rows, torch.stack([send_splits, recv_splits]), order
 
     def gather_ancestors(self, us_local: torch.Tensor, A_full: torch.Tensor, take_rows) -> torch.Tensor:
-        """us_prev_local[m] = us_full[A_full[offset + m]] without ever materialising us_full."""
+        """us_prev_local[m] = us_full[A_full[offset + m]] by the all-to-all (us_full is never materialised)."""
         if self.world == 1:
             return take_rows(us_local, A_full)
-        send_rows, send_splits, recv_splits, order = self.exchange_plan(A_full)
+        send_rows, splits, order = self.exchange_plan(A_full)
+        sp = splits.cpu().tolist()                                # the one host copy of the step: 2 x world integers
         rowshape = tuple(us_local.shape[1:])
-        send = take_rows(us_local, send_rows.to(torch.int32)).reshape(len(send_rows), -1).contiguous()
-        recv = torch.empty((self.n, send.shape[1]), dtype=us_local.dtype, device=us_local.device)
-        self.dist.all_to_all_single(recv, send, output_split_sizes=recv_splits, input_split_sizes=send_splits,
-                                    group=self.group)
+        send = take_rows(us_local, send_rows.to(torch.int32)).reshape(send_rows.numel(), -1).contiguous()
+        recv = torch.empty((self.count, send.shape[1]), dtype=us_local.dtype, device=us_local.device)
+        self.dist.all_to_all_single(recv, send, output_split_sizes=sp[1], input_split_sizes=sp[0], group=self.group)
+        self.bytes_moved += (self.count - sp[1][self.rank]) * send.shape[1] * send.element_size()
         out = torch.empty_like(recv)
         out[order] = recv
-        return out.reshape((self.n,) + rowshape)
+        return out.reshape((self.count,) + rowshape)
 
     def broadcast_row(self, us_local: torch.Tensor, idx: int) -> torch.Tensor:
         """us_full[idx] on every rank."""
@@ -128,59 +161,85 @@ def _bs_list(bs_star):
 
 def forward_pass(key, us_star, bs_star, vs, ts, init_sampler, init_likelihood_logpdf, transition_sampler,
                  likelihood_logpdf, nrows, shards: ParticleShards, backend=None, **kwargs):
-    """csmc.forward_pass (fbs/samplers/csmc/csmc.py:80-164) with conditional killing resampling on a
-    sharded ensemble of `nrows` particles.  The closures receive ``row_slice=(offset, count, total)``
-    so that per-row randomness can be drawn as a slice of the global draw.
+    """csmc.forward_pass (fbs/samplers/csmc/csmc.py:80-164) with conditional killing resampling on a sharded
+    ensemble of `nrows` rows.  ``init_sampler(key, nrows, row_slice=..., **kw)`` returns the LOCAL rows; the closures
+    receive ``row_slice=(offset, count, total)`` so that per-row randomness is drawn as a slice of the global draw.
 
-    Returns (log_ws_full (N,) normalised, us_local (n, ...))."""
+    Returns (log_ws_full (R,) normalised, us_local (count, ...))."""
     be = backend or gpu_backend()
     sh = shards
-    assert sh.N == nrows
+    assert sh.R == nrows
     nsteps = us_star.shape[0] - 1
     bs = _bs_list(bs_star)
+    pin_of = lambda k: (bs[k] - sh.offset, us_star[k]) if sh.owns(bs[k]) else None
     key_init, key_scan = be.split(key, 2)                                            # csmc.py:150
     us = init_sampler(key_init, nrows, row_slice=sh.row_slice, **kwargs)             # :151 (local rows)
     if sh.owns(bs[0]):
         us = be.set_row(us, bs[0] - sh.offset, us_star[0])                           # :152
     lw = init_likelihood_logpdf(vs[0], us, vs[1], row_slice=sh.row_slice, **kwargs)   # :154 (local)
-    log_ws = be.normalise(sh.all_gather_vec(lw), log_space=True)                      # :155 (replicated)
+    log_ws = be.normalise(sh.all_gather_rows(lw), log_space=True)                     # :155 (replicated)
     keys = be.split(key_scan, nsteps)                                                 # :157
+    closures = (transition_sampler, likelihood_logpdf)
     for k in range(nsteps):                                                           # scan_body :132-148
         key_resampling, key_transition = be.split(keys[k], 2)
         v, v_prev, t_prev = vs[k + 1], vs[k], ts[k]
         A = be.cond_resampling(key_resampling, be.exp(log_ws), bs[k], bs[k + 1], True)  # :139 (replicated)
-        us_prev = sh.gather_ancestors(us, A, be.take_rows)                            # :140 (exchange)
-        us = transition_sampler(us_prev, v_prev, t_prev, key_transition, row_slice=sh.row_slice, **kwargs)  # :142
-        if sh.owns(bs[k + 1]):
-            us = be.set_row(us, bs[k + 1] - sh.offset, us_star[k + 1])                # :143
-        lw = likelihood_logpdf(v, us_prev, v_prev, t_prev, **kwargs)                  # :145 (local)
-        log_ws = be.normalise(sh.all_gather_vec(lw), log_space=True)                  # :146 (gather + replicated)
+        A_local = A[sh.offset:sh.offset + sh.count]
+        if sh.exchange == "all_gather" or sh.world == 1:                              # :140: rows by one collective,
+            us_src, A_src = sh.all_gather_rows(us), A_local                           # gathered through A by the consumer
+            if sh.world > 1:
+                sh.bytes_moved += (sh.R - sh.count) * int(np.prod(us.shape[1:])) * us.element_size()
+        else:                                                                         # :140: only the rows that move
+            us_src, A_src = sh.gather_ancestors(us, A, be.take_rows), None
+        fused = be.fused_step(closures, us_src, A_src, v, v_prev, t_prev, key_transition, pin_of(k + 1), sh.row_slice,
+                              kwargs) if getattr(be, "fused_step", None) else None
+        if fused is not None:                                                         # :140-145 around one evaluation
+            us, lw = fused
+        else:
+            us_prev = us_src if A_src is None else be.take_rows(us_src, A_src)
+            us = transition_sampler(us_prev, v_prev, t_prev, key_transition, row_slice=sh.row_slice, **kwargs)  # :142
+            if sh.owns(bs[k + 1]):
+                us = be.set_row(us, bs[k + 1] - sh.offset, us_star[k + 1])            # :143
+            lw = likelihood_logpdf(v, us_prev, v_prev, t_prev, **kwargs)              # :145 (local)
+        log_ws = be.normalise(sh.all_gather_rows(lw), log_space=True)                 # :146 (gather + replicated)
     return log_ws, us
 
 
 def gibbs_kernel(key, x0, y0, us_star, bs_star, ts, fwd_sampler, sde, unpack, nparticles, transition_sampler,
-                 transition_logpdf, likelihood_logpdf, shards: ParticleShards, backend=None, **kwargs):
-    """gibbs_kernel (fbs/samplers/gibbs.py:68-168; marg_y=False, explicit_backward=True,
-    explicit_final=False) with the particle ensemble sharded over `shards`.  Every rank returns the
+                 transition_logpdf, likelihood_logpdf, shards: ParticleShards, backend=None,
+                 explicit_final: bool = False, **kwargs):
+    """gibbs_kernel (fbs/samplers/gibbs.py:68-168; marg_y=False, explicit_backward=True) with the particle ensemble
+    sharded over `shards` (built for nparticles rows, or nparticles + 1 with explicit_final).  Every rank returns the
     same (x0, us_star, bs_star, acc) as the unsharded kernel."""
     be = backend or gpu_backend()
     sh = shards
+    rows = nparticles + 1 if explicit_final else nparticles
+    if sh.R != rows:
+        raise ValueError(f"the shards describe {sh.R} rows, the sweep has {rows}")
     key_fwd, key_csmc, key_bridge = be.split(key, 3)                                  # :126
     path_xy = fwd_sampler(key_fwd, x0, y0, **kwargs)                                  # :127 (replicated, one path)
     path_x, path_y = unpack(path_xy, **kwargs)
     us = torch.flip(path_x, [0])
     vs = torch.flip(path_y, [0])
+    ts0 = ts[0]
 
-    def init_sampler(key_, n_, row_slice=None, **kw):                                 # :140-141
-        return us[0].unsqueeze(0).expand((sh.n,) + tuple(us.shape[1:])).clone()
+    if explicit_final:                                                                # :132-138
+        def init_sampler(key_, n_, row_slice=None, **kw):
+            return be.normal(key_, (n_,) + tuple(us.shape[1:]), device=us.device, rows=row_slice[:2])
 
-    def init_likelihood_logpdf(v0, u0s, v1, row_slice=None, **kw):                    # :143-144
-        return torch.full((sh.n,), -math.log(nparticles), dtype=torch.float32, device=us.device)
+        def init_likelihood_logpdf(v0, u0s, v1, row_slice=None, **kw):
+            return likelihood_logpdf(v0, u0s, v1, ts0, **kw)
+    else:                                                                             # :139-144
+        def init_sampler(key_, n_, row_slice=None, **kw):
+            return us[0].unsqueeze(0).expand((sh.count,) + tuple(us.shape[1:])).clone()
+
+        def init_likelihood_logpdf(v0, u0s, v1, row_slice=None, **kw):
+            return torch.full((sh.count,), -math.log(nparticles), dtype=torch.float32, device=us.device)
 
     bs_np = np.asarray(bs_star.detach().cpu() if isinstance(bs_star, torch.Tensor) else bs_star).reshape(-1)
     k_fwd, k_x0, k_us, k_bs = be.split(key_csmc, 4)                                   # :147
     log_ws_T, us_T = forward_pass(k_fwd, us, bs_np, vs, ts, init_sampler, init_likelihood_logpdf, transition_sampler,
-                                  likelihood_logpdf, nparticles, sh, be, **kwargs)    # :148
+                                  likelihood_logpdf, rows, sh, be, **kwargs)          # :148
     idx, _ = be.force_move(k_x0, be.exp(log_ws_T), int(bs_np[-1]))                    # :152 (replicated)
     x0_new = sh.broadcast_row(us_T, int(idx))                                         # :154
     us_star_next = torch.flip(unpack(fwd_sampler(k_us, x0_new, y0, **kwargs), **kwargs)[0], [0])  # :155

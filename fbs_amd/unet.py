@@ -508,16 +508,27 @@ def make_st_nn(nn_module: UNet, param=None, device=None):
     vector than the one it currently holds."""
     nn_module = nn_module.to(device) if device is not None else nn_module
     nn_module.eval()
-    state = {"loaded": None}
+    # the vector whose weights the network currently holds: a strong reference (an id() can be recycled once the object is
+    # collected) plus what tells an in-place update apart -- a tensor's version counter, a checksum for anything else
+    state = {"obj": None, "stamp": None}
+
+    def stamp_of(p):
+        if isinstance(p, torch.Tensor):
+            return ("v", p._version)
+        a = np.asarray(p)
+        return ("s", a.shape, float(a.reshape(-1)[:: max(1, a.size // 4096)].astype(np.float64).sum()))
+
+    def load(p):
+        nn_module.load_flat_params(p)
+        state["obj"], state["stamp"] = p, stamp_of(p)
+
     if param is not None:
-        nn_module.load_flat_params(param)
-        state["loaded"] = id(param)
+        load(param)
 
     @torch.no_grad()
     def forward_pass(x, t, p=None):
-        if p is not None and id(p) != state["loaded"]:
-            nn_module.load_flat_params(p)
-            state["loaded"] = id(p)
+        if p is not None and (p is not state["obj"] or stamp_of(p) != state["stamp"]):
+            load(p)
         return nn_module(x, t)
 
     return nn_module.export_flat_params(), None, forward_pass

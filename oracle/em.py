@@ -111,3 +111,28 @@ def transition_logpdf(us, net, mode, cx, cs, dt, sd, u, u_off):
     x = np.asarray(us, F).reshape(net.shape[0], -1)
     d = _drift(mode, cx, cs, x, net[:, u_off])
     return tree_sum_rows(_logpdf_terms(np.asarray(u, F).reshape(1, -1), x, d, dt, sd))
+
+
+def forward_pass(key, us_star, bs, vs, us0, lw0, ts, coef_fn, net_fn, dt, u_off, v_off, role):
+    """csmc.forward_pass (fbs/samplers/csmc/csmc.py:150-159) with conditional killing resampling over the image
+    closures, for a caller-supplied network: net_fn(img (n, D) float32, t_prev) -> (n, D) float32 and
+    coef_fn(t_prev) -> (mode, cx, cs, sd).  us0 (n, du) / lw0 (n,) are the initial particles and log-weights.
+    -> (As (T, n), final normalised log-weights, final particles)."""
+    from . import cond_killing, exp, normalise, split
+    T = us_star.shape[0] - 1
+    _, key_scan = split(key, 2)
+    us = np.array(us0, F)
+    us[bs[0]] = us_star[0]
+    log_ws = normalise(lw0, True)
+    keys = split(key_scan, T)
+    As = []
+    for k in range(T):
+        kr, kt = split(keys[k], 2)
+        A = cond_killing(kr, exp(log_ws), int(bs[k]), int(bs[k + 1]), True)
+        mode, cx, cs, sd = coef_fn(ts[k])
+        net = net_fn(concat(us, A, vs[k], role), ts[k])
+        us, lw = finish(us, A, net, mode, F(cx), F(cs), F(dt), F(sd), vs[k + 1], vs[k], kt, us.shape[0], 0, int(bs[k + 1]),
+                        us_star[k + 1], u_off, v_off)
+        log_ws = normalise(lw, True)
+        As.append(A)
+    return np.stack(As), log_ws, us

@@ -236,27 +236,11 @@ def _bridge(dev, task, shape, T, mode="score"):
     return ds, ScoreBridge(_toy_net, ds, sde, ts, chunk=7, mode=mode), sde, ts
 
 
-def _oracle_forward(O, sb, u_off, v_off, role, key, us_star, bs, vs, us0, lw0, want_path=False):
-    """csmc.forward_pass (fbs/samplers/csmc/csmc.py:150-159) with conditional killing and the image closures."""
+def _oracle_forward(O, sb, u_off, v_off, role, key, us_star, bs, vs, us0, lw0):
+    """oracle/em.py's restatement of csmc.forward_pass over the image closures, with the stand-in network."""
     from oracle import em
-    T = us_star.shape[0] - 1
-    key_init, key_scan = O.split(key, 2)
-    us = us0.copy()
-    us[bs[0]] = us_star[0]
-    log_ws = O.normalise(lw0, True)
-    keys = O.split(key_scan, T)
-    As = []
-    for k in range(T):
-        kr, kt = O.split(keys[k], 2)
-        A = O.cond_killing(kr, O.exp(log_ws), int(bs[k]), int(bs[k + 1]), True)
-        mode, cx, cs, sd = sb._coef(sb.ts[k])
-        img = em.concat(us, A, vs[k], role)
-        net = _toy_net_np(img, sb.T - float(sb.ts[k]))
-        us, lw = em.finish(us, A, net, mode, np.float32(cx), np.float32(cs), np.float32(sb.dt), np.float32(sd),
-                           vs[k + 1], vs[k], kt, us.shape[0], 0, int(bs[k + 1]), us_star[k + 1], u_off, v_off)
-        log_ws = O.normalise(lw, True)
-        As.append(A)
-    return np.stack(As), log_ws, us
+    return em.forward_pass(key, us_star, bs, vs, us0, lw0, sb.ts, sb._coef, lambda img, t: _toy_net_np(img, sb.T - float(t)),
+                           sb.dt, u_off, v_off, role)
 
 
 @pytest.mark.parametrize("task,shape", [("inpaint-15", (28, 28, 1)), ("inpaint-8", (16, 16, 3))])

@@ -8,6 +8,7 @@ export GP100_SWEEPS=3   # keeps the dispatch count of the counter passes small
 tag=${1:-r01}
 out=$PWD/gpurun_out
 export TMPDIR=/tmp
+python3 -c "from fbs_amd import _lib; _lib.build(); import oracle; oracle.build()"   # build before any profiler preload exists
 python3 bench.py > $out/${tag}_bench_stdout.json 2> $out/${tag}_bench_stderr.log
 tail -c 600 $out/${tag}_bench_stdout.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o run -- python3 bench.py --no-cpu-baseline --no-single-chain --batch-scan "" > $out/${tag}_prof.log 2>&1

@@ -1,5 +1,6 @@
 set -e
 export TMPDIR=/tmp
+python3 -c "from fbs_amd import _lib; _lib.build(); import oracle; oracle.build()"   # build before any profiler preload exists
 out=$PWD/gpurun_out
 rm -rf $out/q_prof $out/q_valu
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/q_prof -o run -- python3 bench.py --no-cpu-baseline --no-single-chain --batch-scan "" > $out/q_prof.log 2>&1
