@@ -459,7 +459,10 @@ def main():
     if args.sharded_steps > 0 and not args.no_single_chain:
         del sweep
         torch.cuda.empty_cache()
-        shard = sharded_leg(dev, dist, world, rank, args.sharded_steps)
+        try:
+            shard = sharded_leg(dev, dist, world, rank, args.sharded_steps)
+        except Exception as e:  # every rank runs the same deterministic code: a failure is reported, the headline stays
+            shard = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         out["sharded_c5"] = shard
     if dist is not None:

@@ -79,6 +79,12 @@ class ParticleShards:
         if self.R < self.world:
             raise ValueError(f"an ensemble of {self.R} rows cannot be split over {self.world} ranks")
         self.bytes_moved = 0                                   # payload this rank received in ancestor exchanges
+        # gloo has no device collectives: GPU tensors are staged through the host (multi-rank rehearsals on one GPU box;
+        # the production backend is nccl = RCCL, which takes device pointers)
+        self._stage = dist is not None and dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+    def _h(self, x: torch.Tensor) -> torch.Tensor:
+        return x.cpu() if (self._stage and x.is_cuda) else x
 
     # kept for callers of the round-1 interface
     @property
@@ -102,10 +108,10 @@ class ParticleShards:
         """Every rank's (count, ...) rows -> the full (R, ...) array, on every rank."""
         if self.world == 1:
             return x_local
-        x = self._pad(x_local)
+        x = self._h(self._pad(x_local))
         full = torch.empty((self.world * self.n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         self.dist.all_gather_into_tensor(full, x, group=self.group)
-        return full[:self.R]                                    # shards are contiguous: only the tail is padding
+        return full[:self.R].to(x_local.device)                 # shards are contiguous: only the tail is padding
 
     all_gather_vec = all_gather_rows
 
@@ -135,8 +141,10 @@ class ParticleShards:
         sp = splits.cpu().tolist()                                # the one host copy of the step: 2 x world integers
         rowshape = tuple(us_local.shape[1:])
         send = take_rows(us_local, send_rows.to(torch.int32)).reshape(send_rows.numel(), -1).contiguous()
-        recv = torch.empty((self.count, send.shape[1]), dtype=us_local.dtype, device=us_local.device)
+        send = self._h(send)
+        recv = torch.empty((self.count, send.shape[1]), dtype=us_local.dtype, device=send.device)
         self.dist.all_to_all_single(recv, send, output_split_sizes=sp[1], input_split_sizes=sp[0], group=self.group)
+        recv = recv.to(us_local.device)
         self.bytes_moved += (self.count - sp[1][self.rank]) * send.shape[1] * send.element_size()
         out = torch.empty_like(recv)
         out[order] = recv
@@ -148,8 +156,10 @@ class ParticleShards:
         src = idx // self.n
         row = us_local[idx - self.offset].clone() if src == self.rank else torch.empty_like(us_local[0])
         if self.world > 1:
-            self.dist.broadcast(row, src=src if self.group is None else self.dist.get_global_rank(self.group, src),
+            h = self._h(row)
+            self.dist.broadcast(h, src=src if self.group is None else self.dist.get_global_rank(self.group, src),
                                 group=self.group)
+            row = h.to(row.device)
         return row
 
 

@@ -186,6 +186,7 @@ def test_shards_ragged_split_and_argument_checks():
         def is_initialized(self): return True
         def get_world_size(self, g): return self.w
         def get_rank(self, g): return self.r
+        def get_backend(self, g=None): return "gloo"
     # 10 rows over 3 ranks: shards of 4, 4 and 2 rows
     got = [(s.offset, s.count) for s in (sharded.ParticleShards(10, dist=FakeDist(3, r)) for r in range(3))]
     assert got == [(0, 4), (4, 4), (8, 2)]
