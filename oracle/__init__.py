@@ -670,3 +670,62 @@ def doob_bridge_np(key, A, B, S, ddt, x0, xT, T, nsub, replace):
     if replace:
         out[-1] = tg
     return out
+
+
+def discrete_time_simulator_np(key, x0, ts, f, q):
+    """fbs/sdes/simulators.py:109-123: X(t_{k+1}) = f(X(t_k), t_{k+1}, t_k) + q(t_{k+1}, t_k) w, float32, one
+    rounding per operation; f / q python callables on numpy values."""
+    ts = np.asarray(ts, np.float64)
+    x = _f32(x0).copy()
+    rnds = normal(key, (ts.size - 1,) + x.shape)                                       # :122
+    for k in range(ts.size - 1):
+        x = (_f32(f(x, float(ts[k + 1]), float(ts[k]))) + (np.float32(q(float(ts[k + 1]), float(ts[k]))) * rnds[k]).astype(np.float32)).astype(np.float32)
+    return x
+
+
+def twisted_smc_np(key, y, ts, init_sampler, transition_logpdf, twisting_logpdf, twisting_prop_sampler,
+                   twisting_prop_logpdf, resampling, nparticles):
+    """fbs/samplers/smc.py:261-309 with numpy closures; `resampling(weights, key)` one of this module's resamplers.
+    -> (samples, normalised log-weights, [ancestor indices per step])."""
+    ts = np.asarray(ts, np.float64)
+    nsteps = ts.size - 1
+    key_init, key_filter = split(key, 2)                                               # :298
+    keys = split(key_filter, nsteps)                                                   # :299
+    xs = _f32(init_sampler(key_init, nparticles))                                      # :301
+    log_ps = _f32(twisting_logpdf(y, xs, ts[0]))                                       # :302
+    log_ws = normalise(log_ps, True)                                                   # :303
+    inds_all = []
+    for k in range(nsteps):                                                            # scan over (keys, ts[1:]) :306-307
+        key_resampling, key_prop = split(keys[k], 2)                                   # :281
+        t_prev = ts[k + 1]
+        inds = resampling(exp(log_ws), key_resampling)                                 # :284
+        xs_prev, log_ps_prev = xs[inds], log_ps[inds]                                  # :285-286
+        xs = _f32(twisting_prop_sampler(key_prop, xs_prev, t_prev, y))                 # :289
+        log_ps = _f32(twisting_logpdf(y, xs, t_prev))                                  # :292
+        lw = ((_f32(transition_logpdf(xs, xs_prev, t_prev)) + log_ps).astype(np.float32)
+              - _f32(twisting_prop_logpdf(xs, xs_prev, t_prev, y))).astype(np.float32)
+        log_ws = normalise((lw - log_ps_prev).astype(np.float32), True)                # :293-295
+        inds_all.append(inds)
+    return xs, log_ws, inds_all
+
+
+def gibbs_kernel_lg_marg_y(m: LGModel, key, x0, y0, bs_star, nparticles, bridge):
+    """gibbs_kernel (gibbs.py:68-168) with marg_y=True, explicit_backward=True, explicit_final=False: the observation
+    path is re-drawn by bridge_sampler (gibbs.py:17-20,130).  `bridge(key, y_first, y_last)` -> (T+1, dv) is the
+    Doob-bridge restatement (doob_bridge_np with the caller's coefficient tables)."""
+    x0, y0 = _f32(x0).reshape(m.du), _f32(y0).reshape(m.dv)
+    bs_star = _i32(bs_star)
+    key_fwd, key_csmc, key_bridge = split(key, 3)                                      # :126
+    path = lg_fwd_sampler(m, key_fwd, np.concatenate([x0, y0]))                        # :127
+    path_x, path_y = path[:, :m.du], path[:, m.du:]
+    us = path_x[::-1].copy()                                                           # :129
+    vs = bridge(key_bridge, path_y[0], path_y[-1])[::-1].copy()                        # :130
+    us0 = np.tile(us[0][None, :], (nparticles, 1)).astype(np.float32)                  # :140-141
+    lw0 = np.full(nparticles, -np.log(nparticles), np.float32)                         # :143-144
+    k_fwd, k_x0, k_us, k_bs = split(key_csmc, 4)                                       # :147
+    fw = csmc_forward_pass_lg(m, k_fwd, us, bs_star, vs, us0, lw0, store=False)        # :148
+    idx, _ = force_move(k_x0, exp(fw["lw_last"]), int(bs_star[-1]))                    # :152
+    x0n = fw["us_last"][idx]                                                           # :154
+    us_next = lg_fwd_sampler(m, k_us, np.concatenate([x0n, y0]))[:, :m.du][::-1].copy()  # :155
+    bs_next = randint(k_bs, (m.T + 1,), 0, nparticles)                                 # :156
+    return us_next[-1], us_next, bs_next, bs_next != bs_star                           # :167-168

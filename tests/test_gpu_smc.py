@@ -175,13 +175,50 @@ def test_doob_bridge_and_marg_y_gibbs(oracle, dev):
         free = _np(doob_bridge_simulator(key, sde, torch.from_numpy(x0).to(dev), torch.from_numpy(xT).to(dev),
                                          np.linspace(0, 1, 101), integration_nsteps=100, replace=False))
         np.testing.assert_allclose(free[-1], xT, rtol=5e-2, atol=5e-2)
-    # marg_y=True routes gibbs_kernel through bridge_sampler (closure tier) and still returns a valid state
+
+
+@pytest.mark.parametrize("toy,n,T", [(toy_2d, 20, 12), (toy_4d, 64, 9), (toy_2d, 1000, 5)])
+def test_marg_y_gibbs_sweep_equals_oracle(toy, n, T, oracle, dev):
+    """gibbs_kernel(marg_y=True): the observation path is re-drawn by bridge_sampler = doob_bridge_simulator with 100
+    sub-steps (gibbs.py:17-20,130), then the usual conditional-SMC sweep -- the whole sweep against the oracle."""
     from fbs_amd.samplers import gibbs_kernel
-    toy, ts, br = _setup(toy_2d, 12, 1.0, dev)
-    out = gibbs_kernel(oracle.PRNGKey(2), torch.zeros(1, device=dev), torch.from_numpy(toy["y0"]).to(dev), None,
-                       np.zeros(13, np.int32), ts, br.fwd_sampler, br.sde, br.unpack, 20, br.transition_sampler,
-                       br.transition_logpdf, br.likelihood_logpdf, marg_y=True)
-    assert out[1].shape == (13, 1) and out[2].shape == (13,) and torch.isfinite(out[0]).all()
+    from fbs_amd.sdes.linear import _bridge_drift_coeffs
+    toy, ts, br = _setup(toy, T, 1.0, dev)
+    om = oracle_model_from(oracle, br)
+    nsub = 100
+    A, B, S, ddt = np.zeros(T * nsub), np.zeros(T * nsub), np.zeros(T * nsub), np.zeros(T)
+    for k in range(T):
+        h = abs(ts[k + 1] - ts[k]) / nsub
+        ddt[k] = h
+        for j, t_ in enumerate(np.linspace(ts[k], ts[k + 1] - h, nsub)):
+            A[k * nsub + j], B[k * nsub + j] = _bridge_drift_coeffs(br.sde, float(t_), float(ts[-1]))
+            S[k * nsub + j] = float(br.sde.dispersion(float(t_)))
+    bridge = lambda key_, y_first, y_last: oracle.doob_bridge_np(key_, A, B, S, ddt, y_first, y_last, T, nsub, True)
+    rng = np.random.default_rng(8)
+    x0 = rng.normal(size=br.du).astype(np.float32)
+    bs = rng.integers(0, n, T + 1).astype(np.int32)
+    key = oracle.PRNGKey(2)
+    got = gibbs_kernel(key, torch.from_numpy(x0).to(dev), torch.from_numpy(toy["y0"]).to(dev), None, bs, ts,
+                       br.fwd_sampler, br.sde, br.unpack, n, br.transition_sampler, br.transition_logpdf,
+                       br.likelihood_logpdf, marg_y=True)
+    want = oracle.gibbs_kernel_lg_marg_y(om, key, x0, toy["y0"], bs, n, bridge)
+    for a, b, w in zip(got, want, ("x0", "us_star", "bs_star", "acc")):
+        _eq(_np(a), b, w)
+
+
+def test_discrete_time_simulator_equals_oracle(oracle, dev):
+    """fbs/sdes/simulators.py:109-123."""
+    from fbs_amd.sdes import discrete_time_simulator
+    ts = np.linspace(0, 1.5, 14)
+    key = oracle.PRNGKey(21)
+    x0 = np.array([[0.5, -1.0, 0.25], [2.0, 0.1, -0.75]], np.float32)
+    # closures made of single float32 operations, so that torch and numpy round identically
+    f_t = lambda x, t1, t0: x * float(np.float32(0.9)) + float(np.float32(0.1 * (t1 - t0)))
+    f_n = lambda x, t1, t0: ((x * np.float32(0.9)).astype(np.float32) + np.float32(0.1 * (t1 - t0))).astype(np.float32)
+    q = lambda t1, t0: 0.3 + 0.5 * (t1 - t0)
+    got = discrete_time_simulator(key, torch.from_numpy(x0).to(dev), ts, f_t, q)
+    want = oracle.discrete_time_simulator_np(key, x0, ts, f_n, q)
+    _eq(_np(got), want, "discrete_time_simulator")
 
 
 def test_euler_maruyama_and_reverse_simulator(oracle, dev):
@@ -228,6 +265,44 @@ def test_twisted_smc_runs(oracle, dev):
                          prop_logpdf, stratified, n)
     assert xs.shape == (n, 1) and torch.isfinite(xs).all()
     assert abs(float(torch.exp(lw).sum()) - 1.0) < 1e-4
+
+
+def test_twisted_smc_equals_oracle(oracle, dev):
+    """twisted_smc (fbs/samplers/smc.py:261-309) against its numpy restatement: resampling indices bit for bit, final
+    particles and weights bit for bit.  The closures are Gaussian log-densities spelled as single float32 operations
+    (no transcendental inside), so torch and numpy round identically and nothing but the sampler is compared."""
+    from fbs_amd import ops
+    from fbs_amd.samplers import stratified
+    from fbs_amd.samplers.smc import twisted_smc
+    n, T = 300, 11
+    ts = np.linspace(0, 1, T + 1)
+    y = np.float32(0.7)
+    f32 = np.float32
+
+    def quad(a, b, c2):          # -(c2 (a - b)^2) / 2: subtract, multiply, multiply, multiply -- one rounding each.  No
+        d = a - b                # division: torch divides by a scalar through its reciprocal, numpy does not
+        return ((d * d) * c2) * -0.5
+
+    # torch side
+    yt = torch.tensor(float(y), device=dev)
+    tl_t = lambda xs, xp, t: quad(xs, xp * 0.95, 25.0).reshape(-1)
+    tw_t = lambda y_, xs, t: quad(xs, y_ * (0.5 + 0.25 * float(t)), 2.0).reshape(-1)
+    ps_t = lambda k, xp, t, y_: xp * 0.9 + ops.normal(k, tuple(xp.shape), device=dev) * 0.25
+    pl_t = lambda xs, xp, t, y_: quad(xs, xp * 0.9, 16.0).reshape(-1)
+    init_t = lambda k, m: ops.normal(k, (m, 1), device=dev)
+    # numpy side (the same operations)
+    qn = lambda a, b, c2: ((((a - b).astype(f32) * (a - b).astype(f32)).astype(f32) * f32(c2)).astype(f32) * f32(-0.5)).astype(f32)
+    tl_n = lambda xs, xp, t: qn(xs, (xp * f32(0.95)).astype(f32), 25.0).reshape(-1)
+    tw_n = lambda y_, xs, t: qn(xs, f32(y_ * f32(0.5 + 0.25 * float(t))), 2.0).reshape(-1)
+    ps_n = lambda k, xp, t, y_: ((xp * f32(0.9)).astype(f32) + (oracle.normal(k, xp.shape) * f32(0.25)).astype(f32)).astype(f32)
+    pl_n = lambda xs, xp, t, y_: qn(xs, (xp * f32(0.9)).astype(f32), 16.0).reshape(-1)
+    init_n = lambda k, m: oracle.normal(k, (m, 1))
+    key = oracle.PRNGKey(1)
+    xs, lw = twisted_smc(key, yt, ts, init_t, tl_t, tw_t, ps_t, pl_t, stratified, n)
+    wxs, wlw, winds = oracle.twisted_smc_np(key, y, ts, init_n, tl_n, tw_n, ps_n, pl_n, oracle.stratified, n)
+    _eq(_np(xs), wxs, "twisted_smc particles")
+    _eq(_np(lw), wlw, "twisted_smc log-weights")
+    assert abs(float(torch.exp(lw).sum()) - 1.0) < 1e-4 and len(winds) == T
 
 
 def test_sharded_module_world1_on_gpu(oracle, dev):

@@ -185,3 +185,37 @@ def test_whole_unet_fused_inference_matches_eager(shape, up):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         got16 = net(x, t).float()
     assert (got16 - want).abs().max().item() <= 8e-2 * max(want.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("shape,dim", [((2, 16, 16, 1), 8), ((1, 12, 12, 3), 8)])
+def test_whole_network_against_the_numpy_restatement_of_the_flax_unet(shape, dim):
+    """fbs_amd/unet.py against oracle/unet_np.py, an independent float64 numpy restatement of fbs/nn/unet.py that reads
+    the parameters from ONE flat vector in ravel_pytree order: the torch network's export_flat_params() must be that
+    order (names, nesting, (kh, kw, in, out) kernels), and every convention that the reference leaves to flax defaults
+    (GroupNorm epsilon 1e-6, tanh gelu, l2norm over the token axis, softmax axes, pixel-shuffle channel order) must
+    agree, or the outputs differ."""
+    from oracle import unet_np
+    torch.manual_seed(3)
+    B, H, W, C = shape
+    net = UNet(dt=2.0 / 200, dim=dim, in_channels=C, upsampling="pixel_shuffle", dim_mults=(1, 2, 4)).eval()
+    with torch.no_grad():                       # make every parameter matter (flax / torch zero-initialise some biases)
+        for p_ in net.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))
+    flat = net.export_flat_params().numpy()
+    spec = unet_np.param_spec(dim, C, (1, 2, 4), "pixel_shuffle")
+    assert sum(int(np.prod(s)) for _, s in spec) == flat.size == net.num_flat_params()
+    # the same leaf names in the same order as the torch module's own spec
+    assert ["/".join(p_) for p_, _ in spec] == [name for name, _, _ in net.flat_param_spec()]
+    x = torch.randn(*shape)
+    for t in (0.37, 1.9):
+        with torch.no_grad():
+            got = net(x, t).numpy().reshape(shape)
+        want = unet_np.forward(flat, x.numpy(), t, 2.0 / 200, dim)
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)
+    # a different flat vector through load_flat_params gives the restatement's answer for that vector
+    rng = np.random.default_rng(0)
+    flat2 = (flat + 0.02 * rng.normal(size=flat.size)).astype(np.float32)
+    net.load_flat_params(flat2)
+    with torch.no_grad():
+        got = net(x, 0.5).numpy().reshape(shape)
+    np.testing.assert_allclose(got, unet_np.forward(flat2, x.numpy(), 0.5, 2.0 / 200, dim), rtol=2e-4, atol=2e-4)

@@ -95,30 +95,55 @@ def main():
                                     "launches": cols["SQ_WAVES"][k][1]}
     except SystemExit:
         pass
+    # FETCH_SIZE against a known byte count (tools/fetch_calib.hip reads 512 MiB per launch)
+    calib = None
+    try:
+        cal = pmc_avgs(one(f"{tag}_fetch_calib/**/*counter_collection.csv"), "FETCH_SIZE")
+        calib = {}
+        for kname, (kb, cnt) in cal.items():
+            width = "16_bytes_per_lane" if "dwordx4" in kname else "4_bytes_per_lane"
+            calib[width] = {"kernel": kname, "FETCH_SIZE_KB": kb, "true_KB": 524288.0, "true_over_reported": 524288.0 / kb,
+                            "launches": cnt}
+        json.dump(calib, open(os.path.join(prof, f"{tag}_fetch_calibration.json"), "w"), indent=1)
+    except SystemExit:
+        pass
+    try:
+        shutil.copy(one(f"{tag}_prof_em/**/*kernel_stats.csv"), os.path.join(prof, f"{tag}_em_kernel_stats.csv"))
+        emj = [l for l in open(one(f"{tag}_pmc_em.json")).read().split("\n{", 1)]
+        txt = open(one(f"{tag}_pmc_em.json")).read()
+        json.dump(json.loads(txt[txt.index("{"):]), open(os.path.join(prof, f"{tag}_em_pmc.json"), "w"), indent=1)
+    except (SystemExit, ValueError):
+        pass
     cfg = bench["config"]
     prop = [k for k in fetch if "k_lg_prop" in k]
     if not prop:
         raise SystemExit("no k_lg_prop kernel in the PMC pass")
     k = max(prop, key=lambda n: fetch[n][1])
     fkb, wkb = fetch[k][0], write.get(k, (0.0, 0))[0]
+    f4 = calib["4_bytes_per_lane"]["true_over_reported"] if calib and "4_bytes_per_lane" in calib else None
     traffic = {
         "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
-                   "--steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan ''",
-        "workload": cfg.get("workload"),
-        "kernel": k,
+                   "--steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan '' --image-steps 0 --sharded-steps 0",
+        "workload_text": cfg.get("workload"),
+        "workload": {"nparticles": cfg.get("nparticles"), "nsteps": cfg.get("nsteps"), "nchains": cfg.get("nchains")},
+        "kernel": k.replace("void fbsmi::", ""),
+        "fetch_correction_4_bytes_per_lane": f4,
+        "bytes_per_launch": ((fkb * (f4 or 1.0)) + wkb) * 1024.0,
         "k_lg_prop_FETCH_SIZE_KB": fkb,
         "k_lg_prop_WRITE_SIZE_KB": wkb,
         "k_lg_prop_bytes_per_launch": (fkb + wkb) * 1024.0,
         "algorithmic_bytes_per_launch": bench["roofline"]["bytes_per_launch"],
-        "note": "Raw counters (KB = 1024 B), no gfx950 x2 FETCH correction applied: the guide calibrates that "
-                "correction for 16-B-per-lane streaming reads, these kernels move 4 B per lane.  The counters sit on "
-                "the memory side of the XCD L2s (Infinity-Cache hits included).",
+        "note": "Counters in KB = 1024 B; bytes_per_launch = FETCH_SIZE x the factor measured by tools/fetch_calib.hip for "
+                "4-byte-per-lane reads on this box (fetch_correction_4_bytes_per_lane; 1.0 if the calibration is missing) + "
+                "WRITE_SIZE.  The counters sit on the memory side of the XCD L2s (Infinity-Cache hits included).",
     }
     if valu_json:
         pk = [kk for kk in valu_json if "k_lg_prop" in kk]
         if pk:
             top = max(pk, key=lambda kk: valu_json[kk]["launches"])
             traffic["k_lg_prop_valu_insts_per_launch"] = valu_json[top]["valu_per_wave"] * valu_json[top]["waves_per_launch"]
+            traffic["valu_insts_per_launch"] = traffic["k_lg_prop_valu_insts_per_launch"]
+            traffic["cycles_per_valu_inst"] = 2.7   # tools/valu_rate.hip / tools/int_rate.hip: 2.3 (two-operand) .. 4.2 (three-operand)
         traffic["step_kernels_instruction_mix"] = valu_json
     json.dump(traffic, open(os.path.join(prof, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
