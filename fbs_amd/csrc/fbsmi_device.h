@@ -112,6 +112,17 @@ __device__ __forceinline__ bool div_by_in_range(float a) {
     return ((fbsmi_f2u(a) & 0x7fffffffu) - 0x21800000u) <= (0x5d800000u - 0x21800000u);
 }
 
+// the same with ONE residual correction: enough for the two quotients of normal_from_bits on all of its 2^23 arguments
+// (the exhaustive test is the proof; not a general-purpose division)
+__device__ __forceinline__ float div_lean1(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    const float q = a * r;
+    const float rem = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(rem, r, q);
+}
+
 __device__ __forceinline__ float normal_from_bits(uint32_t bits) {
     const float lo = -0.99999994f;
     float x = fbsmi_bits_to_unit(bits) * 2.0f + lo;            // fbsmi_bits_to_normal
@@ -122,7 +133,7 @@ __device__ __forceinline__ float normal_from_bits(uint32_t bits) {
     const int e = (int)(ix >> 23) - 127;
     ix = (ix & 0x007fffffu) + 0x3f3504f3u;
     const float f = fbsmi_u2f(ix) - 1.0f;
-    const float s = div_lean(f, 2.0f + f);
+    const float s = div_lean1(f, 2.0f + f);
     const float z = s * s;
     const float w4 = z * z;
     const float t1 = w4 * (0.40000972152f + w4 * 0.24279078841f);
@@ -131,7 +142,7 @@ __device__ __forceinline__ float normal_from_bits(uint32_t bits) {
     const float hfsq = 0.5f * f * f;
     const float dk = (float)e;
     const float lg = dk * 6.9313812256e-01f - ((hfsq - (s * (hfsq + R) + dk * 9.0580006145e-06f)) - f);
-    const float l1p = u == 1.0f ? y : lg * div_lean(y, u - 1.0f);
+    const float l1p = u == 1.0f ? y : lg * div_lean1(y, u - 1.0f);
     float w = -l1p;
     float p;
     if (w < 5.0f) {

@@ -23,6 +23,7 @@
 // gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "../../include/fbsmi.h"
@@ -37,7 +38,7 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));           // 
 typedef unsigned short us4u __attribute__((ext_vector_type(4), aligned(2)));  // four bf16, 2-byte aligned
 
 // FBSMI_EM_PROBE (diagnostic builds, tools/build_variants.sh; results are WRONG): 1 no erf_inv, 2 no Threefry and no
-// erf_inv, 3 log-density role without its arithmetic, 4 proposal role without its global loads
+// erf_inv, 3 log-density role without its arithmetic, 4 proposal role without its global loads, 5 (k_em_rows) no log-density
 #ifndef FBSMI_EM_PROBE
 #define FBSMI_EM_PROBE 0
 #endif
@@ -410,6 +411,259 @@ __global__ void __launch_bounds__(kBlock, FBSMI_EM_WAVES) k_em_finish(const EmAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same step as ONE pass over whole rows of the network output (k_em_rows).  Measured on this chip: reading the
+// observed 75 % of a row through the offset table costs as much DRAM time as reading the whole row, and the two roles
+// of k_em_finish do not overlap (both sit on the memory pipeline).  Here a workgroup owns a row: the row of the network
+// output goes to LDS by LDS-DMA (global_load_lds_dwordx4: full-width coalesced, no registers, all of it in flight at
+// once) while the workgroup computes its share of the row's normals; after one barrier both parts of the row are served
+// from LDS through the offset tables -- proposal (4 elements per thread and group of 1024), then the log-density
+// segments (pipelined as in em_row_logpdf, the table / target / base from L2).  PAIR2: the launch covers the whole draw
+// with an even number of rows; the workgroup then takes rows r and r + n/2 one after the other and keeps the second
+// words of its Threefry calls in registers for the second row (the pairing of jax's random_bits).
+// Requirements (else k_em_finish): du % 4 == 0, du <= 4096, row bytes a multiple of 16 that fit the LDS budget.
+// ------------------------------------------------------------------------------------------------
+template <int NETDT>
+__device__ __forceinline__ float lds_net(const void* lnet, int off) {
+    if (NETDT == 0) return ((const float*)lnet)[off];
+    return bf16_to_f32(((const unsigned short*)lnet)[off]);
+}
+
+// four staged values; one wide LDS read when the lane's offsets are consecutive and aligned (conflict-free: neighbouring
+// lanes read neighbouring 16-byte slots), else four 4-way conflicting dword reads
+template <int NETDT>
+__device__ __forceinline__ void lds_net4(const void* lnet, const int (&of)[4], float (&s)[4]) {
+    if (of[3] - of[0] == 3 && (of[0] & 3) == 0) {
+        if (NETDT == 0) {
+            const float4 t = *(const float4*)((const float*)lnet + of[0]);
+            s[0] = t.x; s[1] = t.y; s[2] = t.z; s[3] = t.w;
+        } else {
+            const ushort4 t = *(const ushort4*)((const unsigned short*)lnet + of[0]);
+            s[0] = bf16_to_f32(t.x); s[1] = bf16_to_f32(t.y); s[2] = bf16_to_f32(t.z); s[3] = bf16_to_f32(t.w);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = lds_net<NETDT>(lnet, of[k]);
+    }
+}
+
+// stage the row of `net` that belongs to local row r; the caller waits (vmcnt(0) + barrier) before reading it
+template <int NETDT>
+__device__ __forceinline__ void em_stage_row(const EmArgs& a, int32_t r, void* lnet) {
+    const int esz = NETDT == 0 ? 4 : 2;
+    const int64_t row = (int64_t)(a.net_A ? a.net_A[r] : r) * a.D;
+    const char* g = (const char*)a.net + row * esz;
+    const int rowbytes = a.D * esz;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c * 1024 < rowbytes; c += kWaves) {
+        const int b = c * 1024 + lane * 16;
+        if (b < rowbytes)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + b),
+                                             (__attribute__((address_space(3))) void*)((char*)lnet + c * 1024), 16, 0, 0);
+    }
+}
+
+// log-density of the staged row (PART 0 of em_row_logpdf with the network values read from LDS)
+template <int NETDT, int MODE>
+__device__ __forceinline__ float em_row_logpdf_lds(const EmArgs& a, const void* lnet, float* seg) {
+    const int d = a.dv;
+    const int32_t* __restrict__ offt = a.v_off;
+    const float* __restrict__ basep = a.v_prev;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg = (d + 255) >> 8;
+    const float var = a.sd * a.sd;
+    const float rvar = 1.0f / var;
+    const float lognorm = fbsmi_logf(6.2831855f * var);
+    const int dl = d >= 4 ? ((d - 4) & ~3) : 0;
+    struct Ops { int4 o4; f4u tg, b4; int j0; bool full; };
+    auto issue = [&](int sg) {
+        Ops o;
+        o.j0 = sg * 256 + lane * 4;
+        o.full = sg < nseg && o.j0 + 3 < d;
+        const int jl = o.j0 < dl ? o.j0 : dl;
+        o.o4 = *(const int4*)(offt + jl);
+        o.tg = *(const f4u*)(a.v + jl);
+        o.b4 = *(const f4u*)(basep + jl);
+        return o;
+    };
+    auto compute = [&](const Ops& o, int sg) {
+        float t[4];
+        if (o.full) {
+            const int of[4] = {o.o4.x, o.o4.y, o.o4.z, o.o4.w};
+            const float bb[4] = {o.b4.x, o.b4.y, o.b4.z, o.b4.w};
+            const float g[4] = {o.tg.x, o.tg.y, o.tg.z, o.tg.w};
+            float sq[4], sv4[4];
+            lds_net4<NETDT>(lnet, of, sv4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float sv = sv4[k];
+                const float dr = em_drift<MODE>(a.cx, a.cs, bb[k], sv);
+                const float m = bb[k] + dr * a.dt;
+                const float df = g[k] - m;
+                sq[k] = df * df;
+            }
+            const bool lean = __all(div_by_in_range(fmaxf(fmaxf(sq[0], sq[1]), fmaxf(sq[2], sq[3]))) &&
+                                    div_by_in_range(fminf(fminf(sq[0], sq[1]), fminf(sq[2], sq[3]))));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float q = lean ? div_by(sq[k], var, rvar) : sq[k] / var;
+                t[k] = (lognorm + q) * -0.5f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t[k] = 0.0f;
+                if (o.j0 + k < d) {
+                    const float sv = lds_net<NETDT>(lnet, offt[o.j0 + k]);
+                    const float bv = basep[o.j0 + k];
+                    const float dr = em_drift<MODE>(a.cx, a.cs, bv, sv);
+                    const float m = bv + dr * a.dt;
+                    const float df = a.v[o.j0 + k] - m;
+                    const float q = (df * df) / var;
+                    t[k] = (lognorm + q) * -0.5f;
+                }
+            }
+        }
+        float sum = (t[0] + t[1]) + (t[2] + t[3]);
+        TreePath path;
+        sum = wave_upsweep(sum, path);
+        if (lane == 0) seg[sg] = sum;
+    };
+    int sg = wave;
+    if (d < 4) {
+        Ops none;
+        none.j0 = lane * 4;
+        none.full = false;
+        if (sg < nseg) compute(none, sg);
+        sg = nseg;
+    }
+    Ops oa, ob;
+    if (sg < nseg) oa = issue(sg);
+    while (sg < nseg) {
+        ob = issue(sg + kWaves);
+        compute(oa, sg);
+        sg += kWaves;
+        if (sg >= nseg) break;
+        oa = issue(sg + kWaves);
+        compute(ob, sg);
+        sg += kWaves;
+    }
+    __syncthreads();
+    float root = 0.0f;
+    if (nseg <= 64) {
+        if (wave == 0) {
+            float x = lane < nseg ? seg[lane] : 0.0f;
+            TreePath path;
+            root = wave_upsweep(x, path);
+        }
+    } else {
+        float* cur = seg;
+        float* nxt = seg + nseg;
+        int m = nseg;
+        while (m > 1) {
+            const int h = m >> 1;
+            for (int i = threadIdx.x; i < h; i += kBlock) nxt[i] = cur[2 * i] + cur[2 * i + 1];
+            if ((m & 1) && threadIdx.x == 0) nxt[h] = cur[m - 1];
+            m = h + (m & 1);
+            __syncthreads();
+            float* tsw = cur; cur = nxt; nxt = tsw;
+        }
+        root = cur[0];
+    }
+    return root;
+}
+
+template <int KU, bool PAIR2, int NETDT, int MODE>
+__global__ void __launch_bounds__(kBlock, 3) k_em_rows(const EmArgs a, int lnet_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    void* lnet = (void*)lds_raw;
+    float* seg = (float*)(lds_raw + lnet_bytes);
+    const uint32_t du = (uint32_t)a.du;
+    const int32_t r0 = blockIdx.x;                      // first (or only) row of this workgroup
+    const int nrows = PAIR2 ? 2 : 1;
+    const int32_t half_rows = a.n >> 1;
+
+    em_stage_row<NETDT>(a, r0, lnet);
+    // this thread's proposal groups: p = 4 * (tid + 256 k)
+    int4 o4[KU];
+    uint32_t hi[KU][4];
+    float z[KU][4];
+    float4 x4[KU];
+    {
+        const int64_t src = a.A ? (int64_t)a.A[r0] : (int64_t)r0;
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            const uint32_t p = 4u * (threadIdx.x + 256u * k);
+            const uint32_t pl = p < du ? p : du - 4;    // clamped: loads are never predicated
+            o4[k] = *(const int4*)(a.u_off + pl);
+            x4[k] = *(const float4*)(a.us + src * du + pl);
+        }
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            const uint32_t p = 4u * (threadIdx.x + 256u * k);
+            const uint32_t e0 = a.first_el + (uint32_t)r0 * du + p;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t lo;
+                if (FBSMI_EM_PROBE == 2) { lo = e0 + j; hi[k][j] = lo; }
+                else if (PAIR2) threefry2x32(a.k0, a.k1, e0 + j, e0 + j + a.half, lo, hi[k][j]);
+                else lo = random_bits_at(a.k0, a.k1, a.ntot_el, (uint64_t)e0 + j);
+                z[k][j] = (FBSMI_EM_PROBE == 1 || FBSMI_EM_PROBE == 2) ? fbsmi_u2f(lo >> 9) : normal_from_bits(lo);
+            }
+        }
+    }
+    for (int rr = 0; rr < nrows; ++rr) {
+        const int32_t r = rr == 0 ? r0 : r0 + half_rows;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this row (and the operand loads) have landed
+        __syncthreads();
+        // ---- proposal for row r ----
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            const uint32_t p = 4u * (threadIdx.x + 256u * k);
+            if (p < du) {
+                const int of[4] = {o4[k].x, o4[k].y, o4[k].z, o4[k].w};
+                const float xs[4] = {x4[k].x, x4[k].y, x4[k].z, x4[k].w};
+                float y[4], sv4[4];
+                lds_net4<NETDT>(lnet, of, sv4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sv = sv4[j];
+                    const float dr = em_drift<MODE>(a.cx, a.cs, xs[j], sv);
+                    const float m = xs[j] + dr * a.dt;
+                    const float nz = a.sd * z[k][j];
+                    y[j] = m + nz;
+                }
+                float4 out = make_float4(y[0], y[1], y[2], y[3]);
+                if (r == a.pin_row) {
+                    const f4u pv = *(const f4u*)(a.pin_value + p);
+                    out = make_float4(pv.x, pv.y, pv.z, pv.w);
+                }
+                *(float4*)(a.us_new + (int64_t)r * du + p) = out;
+            }
+        }
+        // ---- log-density of row r ----
+        const float root = FBSMI_EM_PROBE == 5 ? 0.0f : em_row_logpdf_lds<NETDT, MODE>(a, lnet, seg);
+        if (threadIdx.x == 0) a.lw[r] = root;
+        if (PAIR2 && rr == 0) {
+            __syncthreads();                                 // everyone is done with the staged row and the segment sums
+            const int32_t r2 = r0 + half_rows;
+            em_stage_row<NETDT>(a, r2, lnet);
+            const int64_t src = a.A ? (int64_t)a.A[r2] : (int64_t)r2;
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                const uint32_t p = 4u * (threadIdx.x + 256u * k);
+                const uint32_t pl = p < du ? p : du - 4;
+                x4[k] = *(const float4*)(a.us + src * du + pl);
+            }
+#pragma unroll
+            for (int k = 0; k < KU; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    z[k][j] = (FBSMI_EM_PROBE == 1 || FBSMI_EM_PROBE == 2) ? fbsmi_u2f(hi[k][j] >> 9) : normal_from_bits(hi[k][j]);
+        }
+    }
+}
+
 template <int NETDT, int MODE>
 __global__ void __launch_bounds__(kBlock) k_em_translp(const EmArgs a) {
     extern __shared__ float seg[];
@@ -431,21 +685,39 @@ __global__ void __launch_bounds__(kBlock) k_em_concat(const float* __restrict__ 
     const int base = c * (1024 * kCatGroups) + threadIdx.x * 4;
     const float* __restrict__ row = us + (int64_t)(A ? A[r] : r) * du;
     if (VEC) {
+        // role words of all groups, then one 16-byte load per group wherever its four sources are consecutive (inside a
+        // run of the mask: four unobserved elements of the ancestor's row, or four observed ones of v_prev) -- the address
+        // unit takes four lanes per cycle whatever the width, so element-wise gathers cost four times as much; groups
+        // across two runs take the element-wise path, for the whole wave (loads are never predicated per lane)
         int4 ro[kCatGroups];
+        const int dl = (D - 4) & ~3;
 #pragma unroll
-        for (int g = 0; g < kCatGroups; ++g)
-            if (base + g * 1024 < D) ro[g] = *(const int4*)(role + base + g * 1024);
+        for (int g = 0; g < kCatGroups; ++g) {
+            const int e = base + g * 1024;
+            ro[g] = *(const int4*)(role + (e < dl ? e : dl));
+        }
         float x[kCatGroups][4];
 #pragma unroll
-        for (int g = 0; g < kCatGroups; ++g)
-            if (base + g * 1024 < D) {
+        for (int g = 0; g < kCatGroups; ++g) {
+            const bool valid = base + g * 1024 < D;
+            const int o0 = ro[g].x, o3 = ro[g].w;
+            const bool urun = o0 >= 0 && o3 == o0 + 3, vrun = o0 < 0 && o3 == o0 - 3;
+            // clamped so that the wide load stays inside its array whatever the lane holds
+            const int uo = o0 >= 0 ? (o0 < du - 4 ? o0 : du - 4) : 0;
+            const int vq = o0 < 0 ? ((~o0) < (D - du) - 4 ? (~o0) : (D - du) - 4) : 0;
+            const float* __restrict__ src = o0 >= 0 ? row + uo : v_prev + (vq > 0 ? vq : 0);
+            const f4u w = *(const f4u*)src;
+            x[g][0] = w.x; x[g][1] = w.y; x[g][2] = w.z; x[g][3] = w.w;
+            if (__any(valid && !(urun || vrun))) {
                 const int o[4] = {ro[g].x, ro[g].y, ro[g].z, ro[g].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float* __restrict__ src = o[k] >= 0 ? row + o[k] : v_prev + ~o[k];
-                    x[g][k] = *src;
+                    const float* __restrict__ s1 = o[k] >= 0 ? row + o[k] : v_prev + ~o[k];
+                    const float xv = *s1;
+                    x[g][k] = (urun || vrun) ? x[g][k] : xv;
                 }
             }
+        }
 #pragma unroll
         for (int g = 0; g < kCatGroups; ++g)
             if (base + g * 1024 < D) {
@@ -494,6 +766,27 @@ int launch_finish(const EmArgs& a, int net_dtype, int mode, size_t lds, hipStrea
     return FBSMI_OK;
 }
 
+template <int KU, bool PAIR2>
+int launch_rows(const EmArgs& a, int net_dtype, int mode, int lnet_bytes, size_t lds, hipStream_t st) {
+    const dim3 grid((unsigned)(PAIR2 ? a.n / 2 : a.n));
+    if (net_dtype == 0 && mode == 0) k_em_rows<KU, PAIR2, 0, 0><<<grid, kBlock, lds, st>>>(a, lnet_bytes);
+    else if (net_dtype == 0) k_em_rows<KU, PAIR2, 0, 1><<<grid, kBlock, lds, st>>>(a, lnet_bytes);
+    else if (mode == 0) k_em_rows<KU, PAIR2, 1, 0><<<grid, kBlock, lds, st>>>(a, lnet_bytes);
+    else k_em_rows<KU, PAIR2, 1, 1><<<grid, kBlock, lds, st>>>(a, lnet_bytes);
+    FBSMI_LAUNCH_CHECK();
+    return FBSMI_OK;
+}
+
+template <bool PAIR2>
+int launch_rows_ku(int ku, const EmArgs& a, int net_dtype, int mode, int lnet_bytes, size_t lds, hipStream_t st) {
+    switch (ku) {
+        case 1: return launch_rows<1, PAIR2>(a, net_dtype, mode, lnet_bytes, lds, st);
+        case 2: return launch_rows<2, PAIR2>(a, net_dtype, mode, lnet_bytes, lds, st);
+        case 3: return launch_rows<3, PAIR2>(a, net_dtype, mode, lnet_bytes, lds, st);
+        default: return launch_rows<4, PAIR2>(a, net_dtype, mode, lnet_bytes, lds, st);
+    }
+}
+
 size_t seg_lds_bytes(int d) {
     const int nseg = (d + 255) >> 8;
     return sizeof(float) * (size_t)(nseg <= 64 ? 64 : 2 * nseg);
@@ -519,7 +812,8 @@ int fbsmi_em_concat(const fbsmi_em_mask* mask, const float* us, const int32_t* A
     const int32_t D = mask->du + mask->dv;
     const int32_t chunks = (D + 1024 * kCatGroups - 1) / (1024 * kCatGroups);
     FBSMI_NEED(n * chunks < (int64_t)1 << 31, "em_concat: too many rows");
-    const bool vec = D % 4 == 0 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)mask->role & 15) == 0;
+    const bool vec = D % 4 == 0 && mask->du >= 4 && mask->dv >= 4 && ((uintptr_t)img & 15) == 0 &&
+                     ((uintptr_t)mask->role & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(n * chunks));
 #define FBSMI_CC(OD, V) \
@@ -567,6 +861,22 @@ int fbsmi_em_finish(const fbsmi_em_mask* mask, const float* us, const int32_t* A
                "em_finish: the mask tables must be 16-byte aligned");
     const size_t lds = seg_lds_bytes(mask->dv);
     hipStream_t st = (hipStream_t)stream;
+    // A rank's row slice of a sharded ensemble cannot pair the Threefry words, and its proposal groups then cost the
+    // two-role kernel 96 us at the config-5 share; one pass over whole rows (k_em_rows) does it in 56.  The whole draw
+    // stays on the two-role kernel (49 us against 62).  FBSMI_EM_ROWS=0 forces the two-role kernel (diagnostics).
+    {
+        static const int rows_on = [] { const char* e = getenv("FBSMI_EM_ROWS"); return e ? atoi(e) : 1; }();
+        const int esz = net_dtype == 0 ? 4 : 2;
+        const int64_t rowbytes = (int64_t)a.D * esz;
+        const int lnet_bytes = (int)((rowbytes + 1023) / 1024 * 1024);
+        const bool rows_ok = rows_on && !pair && us_new && lw && vec && mask->dv >= 1 && mask->du <= 4096 && rowbytes % 16 == 0 &&
+                             lnet_bytes + (int64_t)lds <= 52 * 1024 && (((uintptr_t)net) & 15) == 0 && n >= 64;
+        if (rows_ok) {
+            const int ku = (mask->du + 1023) / 1024;
+            const size_t tot = (size_t)lnet_bytes + lds;
+            return launch_rows_ku<false>(ku, a, net_dtype, mode, lnet_bytes, tot, st);
+        }
+    }
     if (pair) return vec ? launch_finish<true, true>(a, net_dtype, mode, lds, st)
                          : launch_finish<true, false>(a, net_dtype, mode, lds, st);
     return vec ? launch_finish<false, true>(a, net_dtype, mode, lds, st)
