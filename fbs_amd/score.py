@@ -124,13 +124,16 @@ class ScoreBridge:
         self._mark("concat1")
         tf = self.T - float(t_prev)
         out = None
-        for s in range(0, n, self.chunk):
-            y = self.score_fn(img[s:s + self.chunk], tf)
+        # near-equal chunks of at most `chunk` rows: explicit_final's N + 1 rows must not cost a whole network call for one row
+        nchunks = -(-n // self.chunk)
+        per = -(-n // nchunks)
+        for s in range(0, n, per):
+            y = self.score_fn(img[s:s + per], tf)
             if out is None:
                 if y.dtype not in _NET_DT:
                     y = y.float()
                 out = self._buffer("net", (n, em.D), y.dtype, us.device)
-            out[s:s + self.chunk] = y.reshape(-1, em.D)
+            out[s:s + per] = y.reshape(-1, em.D)
         self._mark("net1")
         return out
 

@@ -271,7 +271,7 @@ def test_forward_pass_with_score_bridge_equals_oracle(task, shape, oracle, dev):
     As, lws, uss = forward_pass(key, t(us_star).reshape(T + 1, p, c), bs, t(vs).reshape(T + 1, q, c), ts,
                                 lambda k_, m_: t(us0).reshape(n + 1, p, c), lambda v0, u0s, v1, **kw: t(lw0),
                                 sb.transition_sampler, sb.likelihood_logpdf, killing, n, mask_=mask)
-    assert calls["n"] == T * -(-(n + 1) // 7)          # one network evaluation per step (chunks of 7)
+    assert calls["n"] == T * -(-(n + 1) // 7)          # one network evaluation per step (chunks of at most 7)
     wAs, wlw, wus = _oracle_forward(oracle, sb, u_off, v_off, role, key, us_star, bs, vs, us0, lw0)
     _eq(_np(As), wAs, "As")
     _eq(_np(uss[-1]).reshape(n + 1, -1), wus, "final particles")

@@ -12,10 +12,13 @@ ap.add_argument("--configs", default="c3,c4,c5")
 ap.add_argument("--nsteps", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--rows", type=int, default=0, help="particles on this GPU (0: the configuration's per-GPU share)")
+ap.add_argument("--find", type=int, default=0, help="1: torch.backends.cudnn.benchmark (MIOpen find mode)")
+ap.add_argument("--chunk", type=int, default=0)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = bool(args.find)
 for name in args.configs.split(","):
-    c = image_configs.make(name, dev, dtype=args.dtype, nsteps=args.nsteps)
+    c = image_configs.make(name, dev, dtype=args.dtype, nsteps=args.nsteps, chunk=args.chunk or None)
     n = args.rows or c.shard_rows
     image_configs.gibbs_sweep(c, ops.PRNGKey(3), n)
     torch.cuda.synchronize(); image_configs.network_ms(c)
@@ -30,4 +33,4 @@ for name in args.configs.split(","):
                       "dtype": args.dtype, "ms_per_step": dt / T * 1e3, "network_ms_per_step": net_ms / T,
                       "sampler_ms_per_step": (dt * 1e3 - net_ms) / T, "particle_steps_per_s": n * T / dt,
                       "concat_kernel_us": ev("concat0", "concat1") * 1e3, "finish_kernel_us": ev("finish0", "finish1") * 1e3,
-                      "network_calls": c.timers["calls"]}), flush=True)
+                      "network_calls": c.timers["calls"], "find": args.find, "chunk": c.cfg["chunk"]}), flush=True)
