@@ -267,10 +267,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one rank per GPU over RCCL; FBSMI_BENCH_BACKEND=gloo lets the multi-rank path be rehearsed on one GPU
         backend = os.environ.get("FBSMI_BENCH_BACKEND", "nccl")
+        import datetime
+        tmo = datetime.timedelta(seconds=300)   # a rank that dies inside a collective must not hold the others for the default 10 min
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
     import fbs_amd
     from fbs_amd.sdes import StationaryConstLinearSDE

@@ -26,15 +26,14 @@ from .unet import UNet
 
 CONFIGS = {
     "c3": dict(task="inpaint-15", image=(28, 28, 1), T=2.0, nsteps=1000, nparticles=4096, ngpus=1, mode="score",
-               ef=True, chunk=4224),
+               ef=True, chunk=1024),
     "c4": dict(task="supr-4", image=(28, 28, 1), T=0.5, nsteps=50, nparticles=8192, ngpus=4, mode="drift", ef=True,
-               chunk=2112),
+               chunk=1024),
     "c5": dict(task="inpaint-32", image=(64, 64, 3), T=2.0, nsteps=1000, nparticles=16384, ngpus=8, mode="score",
-               ef=True, chunk=2112),
+               ef=True, chunk=512),
 }
-# chunk = most rows per network call: one call per step for a GPU's share (4097, 2049 rows).  Bigger calls are faster (config 3:
-# 87 ms in one call against 95 in five; config 5: 169 against 183) and every distinct batch size costs MIOpen a kernel build
-# on a fresh machine.
+# chunk = rows per network call.  Power-of-two chunks keep MIOpen on kernels it ships: one call of 4097 / 2049 rows is 8 % faster
+# per step (config 3: 87 ms against 95; config 5: 169 against 183) but costs a fresh machine 50-120 s of kernel builds first.
 
 
 def make(name: str, device, dtype: str = "bf16", nsteps: int | None = None, dim: int = 64, seed: int = 996,
