@@ -89,3 +89,22 @@ def test_sharded_world1_equals_unsharded_with_unet(oracle, dev):
                          sb.transition_logpdf, sb.likelihood_logpdf, mask_=mask)
     network_reproducible = all(torch.equal(u, v) for u, v in zip(a, again))
     assert not network_reproducible, "sharded (world 1) and unsharded sweeps differ although the network is reproducible"
+
+
+@pytest.mark.parametrize("argv", [
+    ["--task", "inpaint", "--rect_size", "15", "--method", "gibbs-eb-ef"],
+    ["--task", "supr", "--rate", "4", "--method", "filter"],
+    ["--task", "inpaint", "--rect_size", "8", "--method", "pmcmc-0.005"],
+    ["--task", "supr", "--rate", "4", "--sb", "--method", "gibbs"],
+])
+def test_image_drivers_run_end_to_end(argv, tmp_path, dev):
+    """examples/imgs_restore.py: the counterparts of experiments/imgs/inpainting.py, supr.py and experiments/sb_imgs/supr.py
+    (same flags and result files), at toy sizes, with a small randomly initialised UNet."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import imgs_restore
+    out = imgs_restore.main(argv + ["--dim", "8", "--nparticles", "12", "--nsamples", "2", "--ny0s", "1", "--test_nsteps", "5",
+                                    "--chunk", "8", "--fp32", "--quiet", "--outdir", str(tmp_path)])
+    assert out.shape == (2, 28, 28, 1) and np.isfinite(out).all()
+    files = sorted(os.listdir(tmp_path))
+    assert any(f.endswith("-true.npz") for f in files) and any(("gibbs" in f or "filter" in f or "pmcmc" in f) and f.endswith(".npy") for f in files)
