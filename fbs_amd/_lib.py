@@ -83,6 +83,7 @@ SIGNATURES = {
     "fbsmi_backtrace": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "fbsmi_linear_path": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
     "fbsmi_affine_em_path": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, C.c_int, _vp, _vp]),
+    "fbsmi_em_update": (C.c_int, [_vp, _vp, _f, _f, _u32, _u32, _i64, _i64, _i64, _vp, _vp]),
     "fbsmi_lg_transition_sampler": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _u32, _u32, _i64, _vp, _vp]),
     "fbsmi_lg_transition_sampler_rows": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _u32, _u32, _i64, _i64, _i64, _vp, _vp]),
     "fbsmi_lg_likelihood_logpdf": (C.c_int, [C.POINTER(LGModelStruct), _i32, _f, _f, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -104,8 +105,10 @@ SIGNATURES = {
                                              _i64, _vp, _vp]),
     # include/fbsmi_nn.h
     "fbsmi_nn_linear_attention": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp]),
-    "fbsmi_nn_channel_layernorm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _vp, _f, _vp, _vp]),
-    "fbsmi_nn_groupnorm_silu": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "fbsmi_nn_channel_layernorm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _vp, _f, _vp, _vp, _vp]),
+    "fbsmi_nn_groupnorm_silu": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fbsmi_nn_bias_add": (C.c_int, [_vp, C.c_int, _i64, _i32, _vp, _vp]),
+    "fbsmi_nn_pixel_shuffle": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
 }
 
 _lib = None

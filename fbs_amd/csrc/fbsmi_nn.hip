@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ xbias,
-                                                        const T* __restrict__ residual) {
+                                                        const T* __restrict__ residual, const float* __restrict__ rbias) {
     const int b = blockIdx.x, t = threadIdx.x;
     const int slots = C >> 3;                 // 8-channel vector slots per token (<= 256 / 8 ... C <= 2048)
     const int spg = slots / groups;           // slots per group
@@ -246,6 +246,9 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
             c[i] = fmaf(xb8[i], a[i], be * sc + sh);   // (x + xbias) * a + c0
         }
         const T* rb = residual ? residual + (size_t)b * n * C + slot * 8 : nullptr;
+        float rb8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb8[i] = (rb && rbias) ? rbias[slot * 8 + i] : 0.0f;
         for (int tok = tl; tok < n; tok += lanes) {
             Vec8 v = ld8(xb + (size_t)tok * C);
 #pragma unroll
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
             if (rb) {
                 const Vec8 r = ld8(rb + (size_t)tok * C);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v.v[i] += r.v[i];
+                for (int i = 0; i < 8; ++i) v.v[i] += r.v[i] + rb8[i];
             }
             st8(yb + (size_t)tok * C, v);
         }
@@ -270,16 +273,21 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
 template <typename T>
 __global__ void __launch_bounds__(256) k_channel_layernorm(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int C,
                                                            const float* __restrict__ scale, float eps,
-                                                           const T* __restrict__ residual) {
+                                                           const T* __restrict__ residual, const float* __restrict__ xbias) {
     const int L = C >> 3;                                   // lanes per row (power of two, <= 64)
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / L;
     const int slot = threadIdx.x % L;
     const bool live = row < rows;
     Vec8 v;
-    if (live) v = ld8(x + row * C + slot * 8);
-    else
+    if (live) {
+        v = ld8(x + row * C + slot * 8);
+        if (xbias)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v.v[i] += xbias[slot * 8 + i];
+    } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v.v[i] = 0.0f;
+    }
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += v.v[i];
@@ -300,6 +308,43 @@ __global__ void __launch_bounds__(256) k_channel_layernorm(const T* __restrict__
         }
         st8(y + row * C + slot * 8, v);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// y[r][c] += bias[c] in place on (rows, C) token-major activations, 8 channels (16 bytes of bfloat16) per thread: what
+// torch's convolution does with a broadcasting elementwise kernel at a fraction of the memory rate.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_bias_add(T* __restrict__ y, const float* __restrict__ bias, int64_t vecs, int C8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= vecs) return;
+    const int slot = (int)(i % C8);
+    Vec8 v = ld8(y + i * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v.v[k] += bias[slot * 8 + k];
+    st8(y + i * 8, v);
+}
+
+// einops 'b h w (h2 w2 c) -> b (h h2) (w w2) c' (fbs/nn/utils.py:53-57) on token-major activations, with the bias of the
+// convolution that produced x added on the way: x (B, H, W, s*s*c) -> y (B, s*H, s*W, c); a thread moves 8 channels.
+template <typename T>
+__global__ void __launch_bounds__(256) k_pixel_shuffle(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ bias,
+                                                       int64_t vecs, int H, int W, int c8, int s) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // output vector index: (((b, oy), ox), cv)
+    if (i >= vecs) return;
+    const int cv = (int)(i % c8);
+    int64_t r = i / c8;
+    const int ox = (int)(r % (W * s));
+    r /= (W * s);
+    const int oy = (int)(r % (H * s));
+    const int64_t b = r / (H * s);
+    const int h2 = oy % s, w2 = ox % s;
+    const int cin = ((h2 * s + w2) * c8 + cv) * 8;
+    Vec8 v = ld8(x + (((b * H + oy / s) * W + ox / s) * (int64_t)(s * s * c8)) * 8 + cin);
+    if (bias)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v.v[k] += bias[cin + k];
+    st8(y + i * 8, v);
 }
 
 }  // namespace fbsmi
@@ -326,7 +371,8 @@ extern "C" int fbsmi_nn_linear_attention(const void* qkv, void* out, int dtype, 
 
 extern "C" int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_t B, int32_t n, int32_t C, int32_t groups,
                                        const float* gamma, const float* beta, float eps, const float* scale,
-                                       const float* shift, const float* xbias, const void* residual, void* stream) {
+                                       const float* shift, const float* xbias, const void* residual, const float* rbias,
+                                       void* stream) {
     if (!x || !y || !gamma || !beta || B < 0 || n < 1 || C < 8 || groups < 1 || groups > 32 || (dtype != 0 && dtype != 1) ||
         (scale == nullptr) != (shift == nullptr))
         return fail(FBSMI_ERR_ARG, "nn_groupnorm_silu: bad arguments");
@@ -337,18 +383,18 @@ extern "C" int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
         k_groupnorm_silu<float><<<(unsigned)B, 256, 0, st>>>((const float*)x, (float*)y, n, C, groups, gamma, beta, eps,
-                                                            scale, shift, xbias, (const float*)residual);
+                                                            scale, shift, xbias, (const float*)residual, rbias);
     else
         k_groupnorm_silu<__hip_bfloat16><<<(unsigned)B, 256, 0, st>>>((const __hip_bfloat16*)x, (__hip_bfloat16*)y, n, C,
                                                                      groups, gamma, beta, eps, scale, shift, xbias,
-                                                                     (const __hip_bfloat16*)residual);
+                                                                     (const __hip_bfloat16*)residual, rbias);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
     return FBSMI_OK;
 }
 
 extern "C" int fbsmi_nn_channel_layernorm(const void* x, void* y, int dtype, int64_t rows, int32_t C, const float* scale,
-                                          float eps, const void* residual, void* stream) {
+                                          float eps, const void* residual, const float* xbias, void* stream) {
     if (!x || !y || !scale || rows < 0 || C < 8 || (dtype != 0 && dtype != 1))
         return fail(FBSMI_ERR_ARG, "nn_channel_layernorm: bad arguments");
     const int L = C / 8;
@@ -361,10 +407,41 @@ extern "C" int fbsmi_nn_channel_layernorm(const void* x, void* y, int dtype, int
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
         k_channel_layernorm<float><<<(unsigned)blocks, 256, 0, st>>>((const float*)x, (float*)y, rows, C, scale, eps,
-                                                                     (const float*)residual);
+                                                                     (const float*)residual, xbias);
     else
         k_channel_layernorm<__hip_bfloat16><<<(unsigned)blocks, 256, 0, st>>>((const __hip_bfloat16*)x, (__hip_bfloat16*)y,
-                                                                             rows, C, scale, eps, (const __hip_bfloat16*)residual);
+                                                                             rows, C, scale, eps, (const __hip_bfloat16*)residual, xbias);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
+    return FBSMI_OK;
+}
+
+extern "C" int fbsmi_nn_bias_add(void* y, int dtype, int64_t rows, int32_t C, const float* bias, void* stream) {
+    if (!y || !bias || rows < 0 || C < 8 || C % 8 != 0 || (dtype != 0 && dtype != 1))
+        return fail(FBSMI_ERR_ARG, "nn_bias_add: bad arguments (C must be a multiple of 8)");
+    const int64_t vecs = rows * (C / 8), blocks = (vecs + 255) / 256;
+    if (vecs == 0) return FBSMI_OK;
+    if (blocks > 0x7fffffff) return fail(FBSMI_ERR_UNSUPPORTED, "nn_bias_add: too many elements");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) k_bias_add<float><<<(unsigned)blocks, 256, 0, st>>>((float*)y, bias, vecs, C / 8);
+    else k_bias_add<__hip_bfloat16><<<(unsigned)blocks, 256, 0, st>>>((__hip_bfloat16*)y, bias, vecs, C / 8);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
+    return FBSMI_OK;
+}
+
+extern "C" int fbsmi_nn_pixel_shuffle(const void* x, void* y, int dtype, int64_t B, int32_t H, int32_t W, int32_t c, int32_t s,
+                                      const float* bias, void* stream) {
+    if (!x || !y || B < 0 || H < 1 || W < 1 || c < 8 || c % 8 != 0 || s < 1 || (dtype != 0 && dtype != 1))
+        return fail(FBSMI_ERR_ARG, "nn_pixel_shuffle: bad arguments (c must be a multiple of 8)");
+    const int64_t vecs = B * H * s * W * s * (c / 8), blocks = (vecs + 255) / 256;
+    if (vecs == 0) return FBSMI_OK;
+    if (blocks > 0x7fffffff) return fail(FBSMI_ERR_UNSUPPORTED, "nn_pixel_shuffle: too many elements");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) k_pixel_shuffle<float><<<(unsigned)blocks, 256, 0, st>>>((const float*)x, (float*)y, bias, vecs, H, W, c / 8, s);
+    else
+        k_pixel_shuffle<__hip_bfloat16><<<(unsigned)blocks, 256, 0, st>>>((const __hip_bfloat16*)x, (__hip_bfloat16*)y, bias, vecs,
+                                                                         H, W, c / 8, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
     return FBSMI_OK;

@@ -60,6 +60,27 @@ __global__ void k_affine_em_path(const uint32_t* keys, const float* A, const flo
     if (replace_last) out[(int64_t)T * D + c] = tg;
 }
 
+// One Euler-Maruyama sub-step for a drift the caller evaluated (any closure: a score network, an SDE's drift):
+//   out = (x + drift * ddt) + c * xi,  xi = element `offset + e` of jax.random.normal(key, (n_total,)) drawn here
+// -- the loop body of euler_maruyama, fbs/sdes/simulators.py:94-99, with c = dispersion(t) * sqrt(ddt); sub-step j of an
+// interval is offset = j * x.size of the (integration_nsteps, *x.shape) draw of simulators.py:91.  Four elements per thread.
+__global__ void __launch_bounds__(256) k_em_update(const float* __restrict__ x, const float* __restrict__ drift, float ddt,
+                                                   float c, uint32_t k0, uint32_t k1, uint64_t n_total, uint64_t offset,
+                                                   int64_t n, float* __restrict__ out) {
+    const int64_t e0 = 4 * (blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
+    if (e0 >= n) return;
+    if (e0 + 4 <= n && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(drift) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + e0), dv = *reinterpret_cast<const float4*>(drift + e0);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (xs[i] + ds[i] * ddt) + c * normal_at(k0, k1, n_total, offset + (uint64_t)(e0 + i));
+        *reinterpret_cast<float4*>(out + e0) = make_float4(o[0], o[1], o[2], o[3]);
+        return;
+    }
+    for (int64_t e = e0; e < n && e < e0 + 4; ++e) out[e] = (x[e] + drift[e] * ddt) + c * normal_at(k0, k1, n_total, offset + (uint64_t)e);
+}
+
 // ---- LG closures on (n, du) row-major particles ---------------------------------------------
 struct LgStep {
     const float* G;
@@ -152,6 +173,18 @@ int fbsmi_affine_em_path(const uint32_t* keys, const float* A, const float* B, c
                "affine_em_path: bad arguments");
     k_affine_em_path<<<grid_for(D, 64), 64, 0, (hipStream_t)stream>>>(keys, A, B, S, ddt, target, x0, T, nsub, D,
                                                                       replace_last, out);
+    FBSMI_LAUNCH_CHECK();
+    return FBSMI_OK;
+}
+
+int fbsmi_em_update(const float* x, const float* drift, float ddt, float c, uint32_t k0, uint32_t k1, int64_t n_total,
+                    int64_t offset, int64_t n, float* out, void* stream) {
+    FBSMI_NEED(n >= 0 && offset >= 0 && n_total >= offset + n && (n == 0 || (x && drift && out)), "em_update: bad arguments");
+    if (n == 0) return FBSMI_OK;
+    const int64_t blocks = ((n + 3) / 4 + 255) / 256;
+    FBSMI_NEED(blocks <= 0x7fffffff, "em_update: too many elements");
+    k_em_update<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(x, drift, ddt, c, k0, k1, (uint64_t)n_total,
+                                                                             (uint64_t)offset, n, out);
     FBSMI_LAUNCH_CHECK();
     return FBSMI_OK;
 }

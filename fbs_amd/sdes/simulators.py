@@ -39,16 +39,27 @@ def euler_maruyama(key, x0, ts, drift, dispersion, integration_nsteps: int = 1, 
         x0 = torch.as_tensor(np.asarray(x0, np.float32), device=ops._default_device())
     ops._require_cuda(x0, "x0")
     keys = ops.split(key, n)
-    x = x0.to(torch.float32)
+    x = x0.to(torch.float32).contiguous()
     path = [x]
+    numel = x.numel()
     for k in range(n):
         t, t_next = float(ts_np[k]), float(ts_np[k + 1])
         ddt = abs(t_next - t) / integration_nsteps
-        rnds = ops.normal(keys[k], (integration_nsteps,) + tuple(x0.shape), device=x0.device)
         sub_ts = np.linspace(t, t_next - ddt, integration_nsteps)
+        k0, k1 = int(keys[k][0]), int(keys[k][1])
         for j in range(integration_nsteps):
             t_ = float(sub_ts[j])
-            x = x + drift(x, t_) * ddt + dispersion(t_) * float(np.sqrt(ddt)) * rnds[j]
+            # x + drift * ddt + dispersion * sqrt(ddt) * rnds[j] with rnds = normal(keys[k], (nsub, *shape)) (:91-99): one
+            # kernel per sub-step, the noise drawn inside it (fbsmi_em_update)
+            f = drift(x, t_)
+            if not (isinstance(f, torch.Tensor) and f.shape == x.shape):
+                f = torch.as_tensor(f, dtype=torch.float32, device=x.device).expand(x.shape)
+            f = f.to(torch.float32).contiguous()
+            c = float(np.float32(float(dispersion(t_)) * float(np.sqrt(ddt))))
+            out = torch.empty_like(x)
+            _lib.call("fbsmi_em_update", x.data_ptr(), f.data_ptr(), float(np.float32(ddt)), c, k0, k1,
+                      integration_nsteps * numel, j * numel, numel, out.data_ptr(), ops._stream())
+            x = out
         if return_path:
             path.append(x)
     return torch.stack(path, dim=0) if return_path else x

@@ -63,9 +63,12 @@ class _ChannelLayerNorm(nn.Module):
         C = x.shape[1]
         return x.is_cuda and not torch.is_grad_enabled() and C % 8 == 0 and (C // 8) <= 64 and ((C // 8) & (C // 8 - 1)) == 0
 
-    def forward(self, x, residual=None):
-        """LayerNorm over channels [+ residual: the attention block's skip connection, added in the same kernel]."""
+    def forward(self, x, residual=None, xbias=None):
+        """LayerNorm over channels of x [+ xbias: the bias of the convolution that produced x] [+ residual: the attention
+        block's skip connection], all in the same kernel."""
         C = x.shape[1]
+        if xbias is not None and not self.fusable(x):
+            x, xbias = x + xbias.to(x.dtype).view(1, -1, 1, 1), None
         if self.fusable(x):
             from . import _lib
             dt = {torch.float32: 0, torch.bfloat16: 1}.get(x.dtype)
@@ -76,7 +79,7 @@ class _ChannelLayerNorm(nn.Module):
             out = torch.empty_like(tok)
             _lib.call("fbsmi_nn_channel_layernorm", tok.data_ptr(), out.data_ptr(), dt, tok.numel() // C, C,
                       self.scale.data_ptr(), float(self.eps), res.data_ptr() if res is not None else None,
-                      torch.cuda.current_stream().cuda_stream)
+                      xbias.data_ptr() if xbias is not None else None, torch.cuda.current_stream().cuda_stream)
             return _nchw_view(out)
         if residual is not None:
             return self.forward(x) + residual
@@ -135,9 +138,9 @@ def _tokens(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
-def _gn_silu(x, norm: nn.GroupNorm, scale, shift, xbias=None, residual=None):
-    """silu(GroupNorm(x + xbias) * (1 + scale) + shift) [+ residual] in one libfbsmi kernel (include/fbsmi_nn.h); x and
-    residual are NCHW (any strides)."""
+def _gn_silu(x, norm: nn.GroupNorm, scale, shift, xbias=None, residual=None, rbias=None):
+    """silu(GroupNorm(x + xbias) * (1 + scale) + shift) [+ residual + rbias] in one libfbsmi kernel (include/fbsmi_nn.h); x
+    and residual are NCHW (any strides)."""
     from . import _lib
     dt = {torch.float32: 0, torch.bfloat16: 1}.get(x.dtype)
     if dt is None:
@@ -150,7 +153,7 @@ def _gn_silu(x, norm: nn.GroupNorm, scale, shift, xbias=None, residual=None):
               norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
               scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None,
               xbias.data_ptr() if xbias is not None else None, res.data_ptr() if res is not None else None,
-              torch.cuda.current_stream().cuda_stream)
+              rbias.data_ptr() if (rbias is not None and res is not None) else None, torch.cuda.current_stream().cuda_stream)
     return _nchw_view(out)
 
 
@@ -173,10 +176,12 @@ class ResnetBlock(nn.Module):
             scale, shift = (p.expand(B, p.shape[1]).contiguous() for p in te.chunk(2, dim=1))
             # the convolution biases are added inside the normalisation kernel (one pass less over the activations)
             h = _gn_silu(self.conv_0(x, with_bias=False), self.norm_0, scale, shift, self.conv_0.conv.bias)
-            if self.res_conv is not None:
-                x = self.res_conv(x)
+            rbias = None
+            if self.res_conv is not None:     # its bias rides on the same kernel as the skip connection it feeds
+                x, rbias = F.conv2d(x, self.res_conv.weight, None), self.res_conv.bias
             # ... and so is the skip connection: x + silu(norm_1(conv_1(h)))
-            return _gn_silu(self.conv_1(h, with_bias=False), self.norm_1, None, None, self.conv_1.conv.bias, residual=x)
+            return _gn_silu(self.conv_1(h, with_bias=False), self.norm_1, None, None, self.conv_1.conv.bias, residual=x,
+                            rbias=rbias)
         h = self.norm_0(self.conv_0(x))
         te = self.time_mlp(F.silu(time_emb))[:, :, None, None]
         scale, shift = te.chunk(2, dim=1)
@@ -226,7 +231,8 @@ class LinearAttention(nn.Module):
     def forward(self, x, residual=None):
         B, C, H, W = x.shape
         if x.is_cuda and self.dim_head == 32 and not torch.is_grad_enabled():
-            return self.to_out_norm(self.to_out(self._fused_core(self.to_qkv(x), B, H, W)), residual)
+            y = F.conv2d(self._fused_core(self.to_qkv(x), B, H, W), self.to_out.weight, None)
+            return self.to_out_norm(y, residual, xbias=self.to_out.bias)
         if residual is not None:
             return self.forward(x) + residual
         q, k, v = self.to_qkv(x).chunk(3, dim=1)
@@ -274,13 +280,56 @@ class AttnBlock(nn.Module):
         return self.attn(self.norm(x)) + x
 
 
+def _kernel_dtype(x):
+    return {torch.float32: 0, torch.bfloat16: 1}.get(x.dtype)
+
+
+def _add_bias(y, bias):
+    """y + bias over the channel axis of an NCHW tensor: in place by fbsmi_nn_bias_add (16-byte vectors) when y is a
+    channels_last inference activation, torch's broadcasting add otherwise."""
+    dt = _kernel_dtype(y)
+    if (y.is_cuda and not torch.is_grad_enabled() and dt is not None and y.shape[1] % 8 == 0
+            and y.is_contiguous(memory_format=torch.channels_last)):
+        from . import _lib
+        _lib.call("fbsmi_nn_bias_add", y.data_ptr(), dt, y.numel() // y.shape[1], y.shape[1], bias.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+        return y
+    return y + bias.to(y.dtype).view(1, -1, 1, 1)
+
+
+def _conv_bias(conv: nn.Conv2d, x):
+    """conv(x) for a convolution whose consumer is not one of libfbsmi's kernels: at inference on the GPU the bias is added
+    by fbsmi_nn_bias_add instead of torch's broadcasting elementwise kernel."""
+    if not (x.is_cuda and not torch.is_grad_enabled() and conv.bias is not None):
+        return conv(x)
+    return _add_bias(F.conv2d(x, conv.weight, None, conv.stride, conv.padding), conv.bias)
+
+
+def _conv_pixel_shuffle(conv: nn.Conv2d, x, scale: int):
+    """pixel_shuffle_nhwc(conv(x), scale), the bias of the convolution added by the shuffle kernel."""
+    c = conv.out_channels // (scale * scale)
+    if not (x.is_cuda and not torch.is_grad_enabled() and c % 8 == 0):
+        return pixel_shuffle_nhwc(conv(x), scale)
+    from . import _lib
+    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+    dt = _kernel_dtype(y)
+    if dt is None:
+        return pixel_shuffle_nhwc(_add_bias(y, conv.bias) if conv.bias is not None else y, scale)
+    B, _, H, W = y.shape
+    tok = _tokens(y)
+    out = torch.empty((B, H * scale, W * scale, c), dtype=tok.dtype, device=tok.device)
+    _lib.call("fbsmi_nn_pixel_shuffle", tok.data_ptr(), out.data_ptr(), dt, B, H, W, c, scale,
+              conv.bias.data_ptr() if conv.bias is not None else None, torch.cuda.current_stream().cuda_stream)
+    return _nchw_view(out)
+
+
 class Downsample(nn.Module):
     def __init__(self, dim_in: int, dim: int):
         super().__init__()
         self.conv = nn.Conv2d(dim_in, dim, 4, stride=2, padding=1)
 
     def forward(self, x):
-        return self.conv(x)
+        return _conv_bias(self.conv, x)
 
 
 class Upsample(nn.Module):
@@ -297,9 +346,8 @@ class Upsample(nn.Module):
     def forward(self, x):
         if self.method == 'resize':
             x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
-            return self.convs[0](x)
-        x = pixel_shuffle_nhwc(self.convs[0](x), 2)
-        return self.convs[1](x)
+            return _conv_bias(self.convs[0], x)
+        return _conv_bias(self.convs[1], _conv_pixel_shuffle(self.convs[0], x, 2))
 
 
 class UNet(nn.Module):
@@ -356,9 +404,14 @@ class UNet(nn.Module):
         if squeeze:
             x = x.unsqueeze(0)
         B = x.shape[0]
-        h = self.init_conv(x.permute(0, 3, 1, 2))      # NHWC -> NCHW view (channels_last strides)
-        if h.is_cuda and h.dtype != torch.float32 and not torch.is_grad_enabled():
-            h = h.contiguous(memory_format=torch.channels_last)   # the whole bf16 network then stays NHWC (MIOpen's fast path)
+        xin = x.permute(0, 3, 1, 2)                    # NHWC -> NCHW view (channels_last strides)
+        if xin.is_cuda and not torch.is_grad_enabled():
+            h = F.conv2d(xin, self.init_conv.weight, None, padding=self.init_conv.padding)
+            if h.dtype != torch.float32:
+                h = h.contiguous(memory_format=torch.channels_last)   # the whole bf16 network then stays NHWC (MIOpen's fast path)
+            h = _add_bias(h, self.init_conv.bias)      # after the layout is settled
+        else:
+            h = self.init_conv(xin)
         hs = [h]
         time = torch.as_tensor(time, dtype=torch.float32, device=x.device)
         emb = sinusoidal_embedding(time / self.dt, out_dim=self.dim)
@@ -372,7 +425,7 @@ class UNet(nn.Module):
             hs.append(h)
             if ind < nres - 1:
                 h = self.down_sample[ind](h)
-        h = self.down_last_conv(h)
+        h = _conv_bias(self.down_last_conv, h)
         h = self.mid_res_1(self.mid_attn(self.mid_res_0(h, emb)), emb)
         for ind in reversed(range(nres)):
             h = self.up_res_0[str(ind)](torch.cat([h, hs.pop()], dim=1), emb)
@@ -380,7 +433,7 @@ class UNet(nn.Module):
             h = self.up_attn[str(ind)](h)
             if ind > 0:
                 h = self.up_sample[str(ind)](h)
-        h = self.up_last_conv(h)
+        h = _conv_bias(self.up_last_conv, h)
         out = self.final_conv(self.final_res(torch.cat([h, hs.pop()], dim=1), emb))
         out = out.permute(0, 2, 3, 1)
         return out[0] if (squeeze or B == 1) else out

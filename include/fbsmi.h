@@ -109,6 +109,13 @@ int fbsmi_affine_em_path(const uint32_t* keys, const float* A, const float* B, c
                          const float* target, const float* x0, int32_t T, int32_t nsub, int64_t D, int replace_last,
                          float* out, void* stream);
 
+/* One Euler-Maruyama sub-step for a drift tensor the caller evaluated (a score network, any closure):
+ *   out[e] = (x[e] + drift[e] * ddt) + c * xi[offset + e],  xi = jax.random.normal(key, (n_total,)) drawn in the kernel,
+ * the loop body of euler_maruyama (fbs/sdes/simulators.py:94-99) with c = dispersion(t) * sqrt(ddt); sub-step j of an interval
+ * is offset = j * n of the (integration_nsteps, *x.shape) draw of simulators.py:91.  out may alias x. */
+int fbsmi_em_update(const float* x, const float* drift, float ddt, float c, uint32_t k0, uint32_t k1, int64_t n_total,
+                    int64_t offset, int64_t n, float* out, void* stream);
+
 /* ---- fused linear-Gaussian sampler ------------------------------------
  * The reverse drift of a scalar-coefficient linear SDE under a Gaussian prior is affine,
  * f(z, t_k) = G_k z + g_k; the three closures of experiments/toy/gp_gibbs.py:120-135 then need no

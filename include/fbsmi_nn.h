@@ -22,22 +22,33 @@ int fbsmi_nn_linear_attention(const void* qkv, void* out, int dtype, int64_t B, 
 /* GroupNorm (biased variance, eps) + per-image channel modulation + SiLU in one pass over the activations --
  * the two normalisation sites of ResnetBlock (fbs/nn/unet.py:127-172):
  *   x' = x + xbias[c]   (the bias of the convolution that produced x, folded in here; NULL: none)
- *   y = silu( ((x' - mean_g) * rsqrt(var_g + eps) * gamma[c] + beta[c]) * (1 + scale[b][c]) + shift[b][c] ) [+ residual]
- * x, y, residual (NULL: none; same layout and dtype as x; the block's skip connection): (B, n, C) token-major
+ *   y = silu( ((x' - mean_g) * rsqrt(var_g + eps) * gamma[c] + beta[c]) * (1 + scale[b][c]) + shift[b][c] ) [+ residual + rbias[c]]
+ * x, y, residual (NULL: none; same layout and dtype as x; the block's skip connection, rbias (NULL: none) the bias of the 1x1
+ * convolution that produced it): (B, n, C) token-major
  * (channels_last); C a multiple of 8 * groups; gamma, beta, xbias: (C) float32;
  * scale, shift: (B, C) float32 or NULL (no modulation).  dtype: 0 float32, 1 bfloat16 (statistics in float32,
  * Welford / Chan merging). */
 int fbsmi_nn_groupnorm_silu(const void* x, void* y, int dtype, int64_t B, int32_t n, int32_t C, int32_t groups,
                             const float* gamma, const float* beta, float eps, const float* scale, const float* shift,
-                            const float* xbias, const void* residual, void* stream);
+                            const float* xbias, const void* residual, const float* rbias, void* stream);
 
 /* LayerNorm over the channel axis without bias (flax nn.LayerNorm(epsilon, use_bias=False), fbs/nn/unet.py:
  * the PreNorm of every attention block and LinearAttention's output norm):
- *   y[r][c] = (x[r][c] - mean_r) * rsqrt(var_r + eps) * scale[c] [+ residual[r][c]],  biased variance over the C
- * channels of row r.  x, y, residual (NULL: none): (rows, C) with C / 8 a power of two <= 64; dtype 0 float32,
- * 1 bfloat16 (statistics in float32). */
+ *   x' = x + xbias[c];  y[r][c] = (x'[r][c] - mean_r) * rsqrt(var_r + eps) * scale[c] [+ residual[r][c]],  biased variance
+ * over the C channels of row r.  x, y, residual (NULL: none): (rows, C) with C / 8 a power of two <= 64; xbias (NULL: none):
+ * (C) float32, the bias of the convolution that produced x; dtype 0 float32, 1 bfloat16 (statistics in float32). */
 int fbsmi_nn_channel_layernorm(const void* x, void* y, int dtype, int64_t rows, int32_t C, const float* scale, float eps,
-                               const void* residual, void* stream);
+                               const void* residual, const float* xbias, void* stream);
+
+/* y[r][c] += bias[c] in place, (rows, C) token-major, C a multiple of 8: the bias of a channels_last convolution whose
+ * consumer is not one of the kernels above. */
+int fbsmi_nn_bias_add(void* y, int dtype, int64_t rows, int32_t C, const float* bias, void* stream);
+
+/* einops 'b h w (h2 w2 c) -> b (h h2) (w w2) c' (fbs/nn/utils.py:53-57; the pixel_shuffle upsampling of fbs/nn/unet.py) with
+ * the bias (NULL: none; (s*s*c) float32) of the convolution that produced x added on the way.
+ * x: (B, H, W, s*s*c) token-major, y: (B, s*H, s*W, c); c a multiple of 8. */
+int fbsmi_nn_pixel_shuffle(const void* x, void* y, int dtype, int64_t B, int32_t H, int32_t W, int32_t c, int32_t s,
+                           const float* bias, void* stream);
 
 #ifdef __cplusplus
 }

@@ -146,10 +146,14 @@ def test_nn_kernels_refuse_unsupported_shapes_loudly():
     with pytest.raises(NotImplementedError):
         _lib.call("fbsmi_nn_linear_attention", p, p, 0, 1, 16, 4, 16, None)          # dim_head != 32
     with pytest.raises(NotImplementedError):
-        _lib.call("fbsmi_nn_groupnorm_silu", p, p, 0, 1, 16, 12, 8, p, p, 1e-6, None, None, None, None, None)   # C % (8 * groups)
+        _lib.call("fbsmi_nn_groupnorm_silu", p, p, 0, 1, 16, 12, 8, p, p, 1e-6, None, None, None, None, None, None)   # C % (8 * groups)
     with pytest.raises(NotImplementedError):
-        _lib.call("fbsmi_nn_channel_layernorm", p, p, 1, 10, 24, p, 1e-5, None, None)      # C / 8 = 3 is not a power of two
+        _lib.call("fbsmi_nn_channel_layernorm", p, p, 1, 10, 24, p, 1e-5, None, None, None)      # C / 8 = 3 is not a power of two
     with pytest.raises(RuntimeError):
         _lib.call("fbsmi_nn_linear_attention", None, p, 0, 1, 16, 4, 32, None)       # null input
     with pytest.raises(RuntimeError):
-        _lib.call("fbsmi_nn_groupnorm_silu", p, p, 2, 1, 16, 64, 8, p, p, 1e-6, None, None, None, None, None)   # unknown dtype
+        _lib.call("fbsmi_nn_groupnorm_silu", p, p, 2, 1, 16, 64, 8, p, p, 1e-6, None, None, None, None, None, None)   # unknown dtype
+    with pytest.raises(RuntimeError):
+        _lib.call("fbsmi_nn_bias_add", p, 1, 10, 12, p, None)                         # C not a multiple of 8
+    with pytest.raises(RuntimeError):
+        _lib.call("fbsmi_nn_pixel_shuffle", p, p, 1, 2, 7, 7, 4, 2, None, None)       # c not a multiple of 8

@@ -230,9 +230,16 @@ def test_euler_maruyama_and_reverse_simulator(oracle, dev):
     disp = lambda t: 1.0 + 0.5 * t
     got = euler_maruyama(key, torch.from_numpy(x0).to(dev), ts, drift, disp, integration_nsteps=3, return_path=True)
     want = oracle.euler_maruyama_np(key, x0, ts, drift, disp, integration_nsteps=3, return_path=True)
-    np.testing.assert_allclose(_np(got), want, rtol=2e-6, atol=2e-6)   # float32, tolerance stated: fp contraction may differ in torch
+    # the update (x + f * ddt) + c * xi is one kernel with the noise drawn inside (fbsmi_em_update, no contraction): given the
+    # same drift values the path is the oracle's bit for bit (the drift here is two float32 multiplications on either side)
+    _eq(_np(got), want, "euler_maruyama path")
     term = euler_maruyama(key, torch.from_numpy(x0).to(dev), ts, drift, disp, integration_nsteps=3)
-    np.testing.assert_allclose(_np(term), want[-1], rtol=2e-6, atol=2e-6)
+    _eq(_np(term), want[-1], "euler_maruyama terminal value")
+    # a ragged size (not a multiple of four, beyond one workgroup) and a scalar-valued drift closure
+    x1 = oracle.normal(oracle.PRNGKey(11), (1027,))
+    got = euler_maruyama(key, torch.from_numpy(x1).to(dev), ts, lambda x, t: 0.25, disp, integration_nsteps=2)
+    want = oracle.euler_maruyama_np(key, x1, ts, lambda x, t: np.float32(0.25), disp, integration_nsteps=2)
+    _eq(_np(got), want, "euler_maruyama ragged")
     # reverse_simulator keeps N(0,1) stationary for the OU process (tests/test_sdes.py:166-194, loose)
     u0 = oracle.normal(oracle.PRNGKey(9), (20000,))
     out = reverse_simulator(oracle.PRNGKey(10), torch.from_numpy(u0).to(dev), np.linspace(0, 1, 65),

@@ -166,6 +166,48 @@ def test_fused_resnet_block_matches_the_torch_ops(B, H, W, din, dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bias_folds_and_pixel_shuffle_kernels(dtype):
+    """fbsmi_nn_bias_add / fbsmi_nn_pixel_shuffle (+ bias) / the xbias of the channel LayerNorm against the torch ops they replace:
+    the float32 results are the same bits (one addition per element either way), bfloat16 rounds once after the addition."""
+    from fbs_amd import _lib
+    from fbs_amd.unet import Upsample, _ChannelLayerNorm, _add_bias, pixel_shuffle_nhwc
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    B, H, W, c = 3, 7, 5, 16
+    y = torch.randn(B, 4 * c, H, W, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(4 * c, device=dev)
+    want = (y.float() + bias.view(1, -1, 1, 1)).to(dtype)
+    with torch.no_grad():
+        got = _add_bias(y.clone(memory_format=torch.preserve_format), bias)
+    assert torch.equal(got, want)
+    # the shuffle on a given convolution output (the convolution itself is MIOpen's and need not be reproducible call to call)
+    want = pixel_shuffle_nhwc((y.float() + bias.view(1, -1, 1, 1)).to(dtype), 2)
+    tok = y.permute(0, 2, 3, 1).contiguous()
+    out = torch.empty((B, 2 * H, 2 * W, c), dtype=dtype, device=dev)
+    _lib.call("fbsmi_nn_pixel_shuffle", tok.data_ptr(), out.data_ptr(), 0 if dtype == torch.float32 else 1, B, H, W, c, 2,
+              bias.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(out.permute(0, 3, 1, 2), want)
+    up = Upsample(2 * c, c, "pixel_shuffle").to(dev).eval()      # and through the module, within the convolution's tolerance
+    x = torch.randn(B, 2 * c, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.enable_grad():
+        want_up = up(x).detach()
+    with torch.no_grad():
+        got_up = up(x)
+    assert got_up.shape == (B, c, 2 * H, 2 * W) and (got_up - want_up).abs().max().item() <= 1e-4 * max(want_up.abs().max().item(), 1.0)
+    ln = _ChannelLayerNorm(4 * c).to(dev)
+    with torch.no_grad():
+        ln.scale.uniform_(0.5, 1.5)
+        res = torch.randn_like(y)
+        got = ln(y, residual=res, xbias=bias).float()
+        xb = y.float() + bias.view(1, -1, 1, 1)
+        ref = (xb - xb.mean(1, keepdim=True)) * torch.rsqrt(xb.var(1, unbiased=False, keepdim=True) + 1e-5) * ln.scale.view(1, -1, 1, 1)
+        ref = ref + res.float()
+    tol = 1e-4 if dtype == torch.float32 else 4e-2
+    assert (got - ref).abs().max().item() <= tol * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape,up", [((3, 28, 28, 1), "pixel_shuffle"), ((2, 32, 32, 3), "resize")])
 def test_whole_unet_fused_inference_matches_eager(shape, up):
     """The inference path (libfbsmi kernels for attention / normalisation glue, cached standardised weights) against

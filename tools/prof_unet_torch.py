@@ -25,4 +25,10 @@ print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_nam
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof2:
     for _ in range(3): fwd()
     torch.cuda.synchronize()
-print(prof2.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=40, max_shapes_column_width=70))
+# self device time per aten op and input shapes, convolutions aside: the glue between the network's kernels
+rows = [e for e in prof2.key_averages(group_by_input_shape=True) if e.self_device_time_total > 0 and e.key.startswith("aten::")]
+rows.sort(key=lambda e: -e.self_device_time_total)
+tot = sum(e.self_device_time_total for e in prof2.key_averages() if e.self_device_time_total > 0)
+print(f"self device time by aten op (3 forwards, total {tot/1e3:.2f} ms)")
+for e in rows[:40]:
+    print(f"{e.key:32s} {e.self_device_time_total/1e3:8.3f} ms {100*e.self_device_time_total/tot:5.1f}% x{e.count:4d}  {str(e.input_shapes)[:110]}")
