@@ -135,6 +135,163 @@ __global__ void __launch_bounds__(256) k_linear_attention(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// to_qkv (1x1 convolution, no bias) + the LinearAttention core in one kernel, bfloat16 on the matrix cores: the
+// (B, n, 3 * heads * 32) tensor between the two never exists.  One workgroup per image, one wave per head.  Per block of 32
+// tokens a wave forms K, V (or Q^T) as 32 x 32 accumulator tiles of v_mfma_f32_32x32x16_bf16 straight from the
+// token-major activations (a lane's operand fragment is 16 contiguous bytes of a token's row; the weight fragments stay
+// in registers), and every later product sums over the ROW index of such a tile, so the tile's registers ARE the next
+// product's operand fragment (converted pairwise to bfloat16) -- no LDS, no lane movement:
+//   pass 1  K = X Wk^T                       -> m_d = max over tokens (d is the lane's column)
+//   pass 2  E = exp(K - m), V = X Wv^T       -> ctx[d][e] += E^T V, Z_d += column sums of E
+//   pass 3  Q^T = Wq X^T, softmax over d (the tile's rows: in-lane + one exchange), out^T = ctx'^T Q'^T, 8-byte stores
+// with ctx' = ctx / (Z_d n) and Q' = softmax(Q) / sqrt(32) (fbs/nn/unet.py:209-245).
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    unsigned p;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(lo), "v"(hi));
+    return p;
+}
+template <int S>
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& x) {   // registers 8S .. 8S+7 as the fragment of k-step S
+    const uint4 u = make_uint4(pk_bf16(x[8 * S], x[8 * S + 1]), pk_bf16(x[8 * S + 2], x[8 * S + 3]),
+                               pk_bf16(x[8 * S + 4], x[8 * S + 5]), pk_bf16(x[8 * S + 6], x[8 * S + 7]));
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+template <int CK>   // C = 16 * CK input channels
+__global__ void __launch_bounds__(256) k_qkv_linear_attention(const __hip_bfloat16* __restrict__ xn,
+                                                              const __hip_bfloat16* __restrict__ w,
+                                                              __hip_bfloat16* __restrict__ out, int n, int heads) {
+    constexpr int C = 16 * CK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
+    const int HD = heads * kHd;
+    const __hip_bfloat16* xb = xn + (size_t)blockIdx.x * n * C;
+    __hip_bfloat16* ob = out + (size_t)blockIdx.x * n * HD;
+    __shared__ float zs[4][kHd];
+    auto load_x = [&](int t0, bf16x8 (&xa)[CK]) {   // operand fragments of tokens t0 .. t0+31 (rows past n: zeros)
+        const int tok = t0 + r;
+        const bool ok = tok < n;
+        const uint4* p = reinterpret_cast<const uint4*>(xb + (size_t)(ok ? tok : n - 1) * C + 8 * h2);
+#pragma unroll
+        for (int s = 0; s < CK; ++s) {
+            uint4 u = p[2 * s];
+            if (!ok) u = make_uint4(0u, 0u, 0u, 0u);
+            xa[s] = __builtin_bit_cast(bf16x8, u);
+        }
+    };
+    auto load_w = [&](int which, int head, bf16x8 (&wf)[CK]) {
+        const uint4* p = reinterpret_cast<const uint4*>(w + (size_t)(which * HD + head * kHd + r) * C + 8 * h2);
+#pragma unroll
+        for (int s = 0; s < CK; ++s) wf[s] = __builtin_bit_cast(bf16x8, p[2 * s]);
+    };
+    auto row_of = [&](int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * h2; };
+    const int iters = (heads + 3) >> 2;
+    for (int it = 0; it < iters; ++it) {
+        const int head = wave + 4 * it;
+        const bool act = head < heads;   // wave-uniform
+        f32x16 ctx;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ctx[i] = 0.0f;
+        float zinv = 0.0f;
+        if (act) {
+            bf16x8 wk[CK], wv[CK], xa[CK];
+            load_w(1, head, wk);
+            // ---- pass 1
+            float m = -__builtin_inff();
+            for (int t0 = 0; t0 < n; t0 += 32) {
+                load_x(t0, xa);
+                f32x16 kk;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) kk[i] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < CK; ++s) kk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[s], wk[s], kk, 0, 0, 0);
+                const bool full = t0 + 32 <= n;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (full || t0 + row_of(i) < n) m = fmaxf(m, kk[i]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            // ---- pass 2
+            load_w(2, head, wv);
+            float z = 0.0f;
+            for (int t0 = 0; t0 < n; t0 += 32) {
+                load_x(t0, xa);
+                f32x16 kk, vv;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { kk[i] = 0.0f; vv[i] = 0.0f; }
+#pragma unroll
+                for (int s = 0; s < CK; ++s) {
+                    kk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[s], wk[s], kk, 0, 0, 0);
+                    vv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[s], wv[s], vv, 0, 0, 0);
+                }
+                const bool full = t0 + 32 <= n;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float e = __expf(kk[i] - m);
+                    if (!full && t0 + row_of(i) >= n) e = 0.0f;   // (V of such a row is zero already: its x is)
+                    z += e;
+                    kk[i] = e;
+                }
+                ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag<0>(kk), acc_frag<0>(vv), ctx, 0, 0, 0);
+                ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag<1>(kk), acc_frag<1>(vv), ctx, 0, 0, 0);
+            }
+            z += __shfl_xor(z, 32);
+            zinv = 1.0f / (z * (float)n);
+            if (h2 == 0) zs[wave][r] = zinv;
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ctx[i] *= zs[wave][row_of(i)];
+            const bf16x8 c0 = acc_frag<0>(ctx), c1 = acc_frag<1>(ctx);
+            bf16x8 wq[CK], xa[CK];
+            load_w(0, head, wq);
+            const float rs = 0.17677669529663687f;   // 1 / sqrt(32)
+            // ---- pass 3
+            for (int t0 = 0; t0 < n; t0 += 32) {
+                load_x(t0, xa);
+                f32x16 qt;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) qt[i] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < CK; ++s) qt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s], xa[s], qt, 0, 0, 0);
+                float mx = qt[0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) mx = fmaxf(mx, qt[i]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    qt[i] = __expf(qt[i] - mx);
+                    sum += qt[i];
+                }
+                sum += __shfl_xor(sum, 32);
+                const float sc = rs / sum;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) qt[i] *= sc;
+                f32x16 o;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[i] = 0.0f;
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, acc_frag<0>(qt), o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, acc_frag<1>(qt), o, 0, 0, 0);
+                const int tok = t0 + r;
+                if (tok < n) {
+                    __hip_bfloat16* op = ob + (size_t)tok * HD + head * kHd + 4 * h2;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        *reinterpret_cast<uint2*>(op + 8 * c) =
+                            make_uint2(pk_bf16(o[4 * c], o[4 * c + 1]), pk_bf16(o[4 * c + 2], o[4 * c + 3]));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // GroupNorm + modulation + SiLU.  One workgroup per image; a thread owns one aligned 8-channel vector slot
 // (always inside one group, since the group size is a multiple of 8) across a strided set of tokens:
 // pass 1 Welford-merges its vectors into (count, mean, M2), the slots of a group are merged through LDS
@@ -442,6 +599,28 @@ extern "C" int fbsmi_nn_pixel_shuffle(const void* x, void* y, int dtype, int64_t
     else
         k_pixel_shuffle<__hip_bfloat16><<<(unsigned)blocks, 256, 0, st>>>((const __hip_bfloat16*)x, (__hip_bfloat16*)y, bias, vecs,
                                                                          H, W, c / 8, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
+    return FBSMI_OK;
+}
+
+extern "C" int fbsmi_nn_qkv_linear_attention(const void* xn, const void* w, void* out, int64_t B, int32_t n, int32_t C,
+                                             int32_t heads, int32_t dim_head, void* stream) {
+    if (!xn || !w || !out || B < 0 || n < 1 || heads < 1) return fail(FBSMI_ERR_ARG, "nn_qkv_linear_attention: bad arguments");
+    if (dim_head != kHd) return fail(FBSMI_ERR_UNSUPPORTED, "nn_qkv_linear_attention: dim_head must be 32");
+    if (C != 16 && C != 32 && C != 64 && C != 128)
+        return fail(FBSMI_ERR_UNSUPPORTED, "nn_qkv_linear_attention: C must be 16, 32, 64 or 128");
+    if (B == 0) return FBSMI_OK;
+    if (B > 0x7fffffff) return fail(FBSMI_ERR_UNSUPPORTED, "nn_qkv_linear_attention: too many images");
+    hipStream_t st = (hipStream_t)stream;
+    const __hip_bfloat16 *x_ = (const __hip_bfloat16*)xn, *w_ = (const __hip_bfloat16*)w;
+    __hip_bfloat16* o_ = (__hip_bfloat16*)out;
+    switch (C) {
+        case 16: k_qkv_linear_attention<1><<<(unsigned)B, 256, 0, st>>>(x_, w_, o_, n, heads); break;
+        case 32: k_qkv_linear_attention<2><<<(unsigned)B, 256, 0, st>>>(x_, w_, o_, n, heads); break;
+        case 64: k_qkv_linear_attention<4><<<(unsigned)B, 256, 0, st>>>(x_, w_, o_, n, heads); break;
+        default: k_qkv_linear_attention<8><<<(unsigned)B, 256, 0, st>>>(x_, w_, o_, n, heads); break;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
     return FBSMI_OK;

@@ -231,7 +231,8 @@ class LinearAttention(nn.Module):
     def forward(self, x, residual=None):
         B, C, H, W = x.shape
         if x.is_cuda and self.dim_head == 32 and not torch.is_grad_enabled():
-            y = F.conv2d(self._fused_core(self.to_qkv(x), B, H, W), self.to_out.weight, None)
+            core = self._fused_qkv_core(x, B, H, W) if self._qkv_fusable(x) else self._fused_core(self.to_qkv(x), B, H, W)
+            y = F.conv2d(core, self.to_out.weight, None)
             return self.to_out_norm(y, residual, xbias=self.to_out.bias)
         if residual is not None:
             return self.forward(x) + residual
@@ -262,7 +263,29 @@ def _linear_attention_core(self, qkv, B, H, W):
     return _nchw_view(out)                             # NCHW view, channel = (head, e)
 
 
+def _qkv_fusable(self, x) -> bool:
+    """bfloat16 activations (the autocast network), C in {16, 32, 64, 128}: to_qkv runs inside the attention kernel."""
+    return (x.dtype == torch.bfloat16 and x.shape[1] in (16, 32, 64, 128)
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _linear_attention_qkv_core(self, x, B, H, W):
+    """to_qkv + softmaxes + both einsums in one libfbsmi kernel on the matrix cores (fbsmi_nn_qkv_linear_attention)."""
+    from . import _lib
+    w0 = self.to_qkv.weight
+    tag = (w0._version, w0.data_ptr(), w0.device)
+    if getattr(self, "_w16_tag", None) != tag:     # the projection's weight in bfloat16, once per weight version
+        self._w16, self._w16_tag = w0.detach().reshape(w0.shape[0], w0.shape[1]).to(torch.bfloat16).contiguous(), tag
+    tok = x.permute(0, 2, 3, 1)                    # (B, H, W, C) view of the channels_last activations
+    out = torch.empty((B, H, W, self.heads * self.dim_head), dtype=torch.bfloat16, device=x.device)
+    _lib.call("fbsmi_nn_qkv_linear_attention", tok.data_ptr(), self._w16.data_ptr(), out.data_ptr(), B, H * W, x.shape[1],
+              self.heads, self.dim_head, torch.cuda.current_stream().cuda_stream)
+    return _nchw_view(out)
+
+
 LinearAttention._fused_core = _linear_attention_core
+LinearAttention._fused_qkv_core = _linear_attention_qkv_core
+LinearAttention._qkv_fusable = _qkv_fusable
 
 
 class AttnBlock(nn.Module):

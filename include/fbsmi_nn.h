@@ -19,6 +19,13 @@ extern "C" {
 int fbsmi_nn_linear_attention(const void* qkv, void* out, int dtype, int64_t B, int32_t n, int32_t heads,
                               int32_t dim_head, void* stream);
 
+/* The same with the to_qkv projection in front (a 1x1 convolution without bias, fbs/nn/unet.py:219-221), bfloat16 on the
+ * matrix cores: qkv = xn W^T is formed tile by tile inside the kernel and never written.
+ * xn: (B, n, C) token-major bfloat16 (the PreNorm output); w: (3 * heads * 32, C) bfloat16, row = which * heads * 32 + head * 32
+ * + d (the convolution's weight); out: (B, n, heads * 32) bfloat16.  C in {16, 32, 64, 128}. */
+int fbsmi_nn_qkv_linear_attention(const void* xn, const void* w, void* out, int64_t B, int32_t n, int32_t C, int32_t heads,
+                                  int32_t dim_head, void* stream);
+
 /* GroupNorm (biased variance, eps) + per-image channel modulation + SiLU in one pass over the activations --
  * the two normalisation sites of ResnetBlock (fbs/nn/unet.py:127-172):
  *   x' = x + xbias[c]   (the bias of the convolution that produced x, folded in here; NULL: none)

@@ -166,6 +166,42 @@ def test_fused_resnet_block_matches_the_torch_ops(B, H, W, din, dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,dim", [(5, 28, 28, 64), (3, 14, 14, 128), (2, 9, 13, 32), (1, 64, 64, 64), (7, 5, 5, 16)])
+def test_fused_qkv_linear_attention_on_the_matrix_cores(B, H, W, dim):
+    """fbsmi_nn_qkv_linear_attention (to_qkv + LinearAttention core, bfloat16 MFMA) against the float32 torch ops of
+    fbs/nn/unet.py:209-245 on the same bfloat16-rounded inputs and weights; the tolerance is bfloat16's (the kernel rounds the
+    softmax numerators, v, the context and q to bfloat16 where the autocast reference rounds qkv and the einsum operands)."""
+    from fbs_amd import _lib
+    from fbs_amd.unet import LinearAttention
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B * 100 + dim)
+    att = LinearAttention(dim).to(dev).eval()
+    x = (torch.randn(B, dim, H, W, device=dev) * 1.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        att.to_qkv.weight.mul_(3.0)                       # spread the logits: softmaxes away from uniform
+        w16 = att.to_qkv.weight.to(torch.bfloat16).float()
+        got = att._fused_qkv_core(x, B, H, W).float()
+        n = H * W
+        qkv = torch.nn.functional.conv2d(x.float(), w16)
+        q, k, v = (t.reshape(B, 4, 32, n).permute(0, 3, 1, 2) for t in qkv.chunk(3, dim=1))
+        q = torch.softmax(q, dim=-1) / 32 ** 0.5
+        k = torch.softmax(k, dim=-3)
+        ctx = torch.einsum('bnhd,bnhe->bhde', k, v / n)
+        want = torch.einsum('bhde,bnhd->bhen', ctx, q).reshape(B, 128, H, W)
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    assert err <= 2e-2 * max(want.abs().max().item(), 1e-6), (err, want.abs().max().item())
+    # through the module under autocast: fused inference path against the eager path
+    xin = torch.randn(B, dim, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.enable_grad():
+            ref = att(xin).detach().float()
+        with torch.no_grad():
+            fused = att(xin.to(torch.bfloat16)).float()
+    assert (fused - ref).abs().max().item() <= 6e-2 * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_bias_folds_and_pixel_shuffle_kernels(dtype):
     """fbsmi_nn_bias_add / fbsmi_nn_pixel_shuffle (+ bias) / the xbias of the channel LayerNorm against the torch ops they replace:
