@@ -292,6 +292,127 @@ __global__ void __launch_bounds__(256) k_qkv_linear_attention(const __hip_bfloat
 }
 
 // ------------------------------------------------------------------------------------------
+// 3 x 3 convolution (stride 1, zero padding 1) on token-major bfloat16 activations as an implicit GEMM on the matrix
+// cores, for the network's narrow layers (Cin = 64 or 128).  A workgroup keeps the weights of its 32 * NB output
+// channels in LDS for its whole life -- [tap][k-step][lane half][channel] 16-byte chunks, so a wave's operand read is
+// 32 consecutive chunks per half, conflict-free -- and walks tiles of 32 * NW output pixels (a wave = 32 pixels x NB
+// accumulator tiles of 32 channels).  The tile's input is the flattened pixel range [p0 - W - 1, p0 + tile + W + 1):
+// it is staged in LDS once (16-byte chunks, one pad chunk per pixel so that 32 consecutive pixels' chunks fall on
+// distinct banks) and all nine taps read their fragments from there -- read straight from memory, nine times, the
+// fragment loads ran at 6.5 TB/s of L2 traffic and were 2/3 of the kernel (tools/bench_conv.py, FBSMI_CONV_PROBE).  The
+// next tile's chunks travel in registers while this tile is multiplied.  The product is formed transposed
+// (out^T = W X^T: output channels in the registers, the pixel on the lane), so a lane stores 4 consecutive channels
+// of its pixel at a time.  Zero padding: a tap whose neighbour is outside the image contributes a zero fragment (the
+// flattened range holds some other pixel there).
+// ------------------------------------------------------------------------------------------
+#ifndef FBSMI_CONV_PROBE
+#define FBSMI_CONV_PROBE 0   // diagnostic builds (tools/build_variants.sh): 1 no activation fragments, 2 no weight reads, 3 no input fetch
+#endif
+template <int CK, int NB, int NW, int MB>   // Cin = 16 * CK; 32 * NB output channels, 32 * MB pixels per wave, NW waves
+__global__ void __launch_bounds__(64 * NW) k_conv3x3(const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w,
+                                                     const float* __restrict__ bias, __hip_bfloat16* __restrict__ y, int H, int W,
+                                                     int Cout, long long npix, long long ntiles) {
+    extern __shared__ uint4 lds[];
+    constexpr int Cin = 16 * CK, kThreads = 64 * NW, kTile = 32 * MB * NW, kNco = 32 * NB;
+    constexpr int kPix = 2 * CK + 1;                 // 16-byte chunks per staged pixel (the last one is padding)
+    uint4* wl = lds;                                 // [9][CK][2][kNco]
+    uint4* patch = lds + 9 * CK * 2 * kNco;          // [kTile + 2 W + 2][kPix]
+    const int co0 = blockIdx.y * kNco;
+    for (int i = threadIdx.x; i < 9 * CK * 2 * kNco; i += kThreads) {
+        const int col = i % kNco, rest = i / kNco, hh = rest & 1, s = (rest >> 1) % CK, tap = (rest >> 1) / CK;
+        wl[i] = *reinterpret_cast<const uint4*>(w + ((size_t)(co0 + col) * 9 + tap) * Cin + 16 * s + 8 * hh);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
+    const int npatch = kTile + 2 * W + 2, nchunk = npatch * 2 * CK;
+    constexpr int kMaxPer = NW == 8 ? 10 : 24;       // staged chunks per thread (host: nchunk <= kMaxPer * kThreads)
+    uint4 stage[kMaxPer];
+    auto fetch = [&](long long t) {                  // tile t's input chunks -> registers (zeros outside the batch)
+        const long long q0 = t * kTile - W - 1;
+#pragma unroll
+        for (int j = 0; j < kMaxPer; ++j) {
+            const int c = threadIdx.x + j * kThreads;
+            const long long q = q0 + c / (2 * CK);
+            uint4 u = make_uint4(0u, 0u, 0u, 0u);
+            if (FBSMI_CONV_PROBE != 3 && c < nchunk && q >= 0 && q < npix)
+                u = *reinterpret_cast<const uint4*>(x + q * Cin + 8 * (c % (2 * CK)));
+            stage[j] = u;
+        }
+    };
+    long long t = blockIdx.x;
+    if (t < ntiles) fetch(t);
+    for (; t < ntiles; t += gridDim.x) {
+        __syncthreads();                             // the previous tile's fragment reads are done (and the weights are in)
+#pragma unroll
+        for (int j = 0; j < kMaxPer; ++j) {
+            const int c = threadIdx.x + j * kThreads;
+            if (c < nchunk) patch[(c / (2 * CK)) * kPix + c % (2 * CK)] = stage[j];
+        }
+        __syncthreads();
+        if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
+        long long p[MB];
+        bool pv[MB];
+        int xw[MB], yh[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            p[mb] = t * kTile + 32 * (MB * wave + mb) + r;
+            pv[mb] = p[mb] < npix;
+            const long long pp = pv[mb] ? p[mb] : npix - 1;
+            xw[mb] = (int)(pp % W);
+            yh[mb] = (int)((pp / W) % H);
+        }
+        const uint4* pc = patch + (32 * MB * wave + r + W + 1) * kPix + h2;   // this lane's first centre pixel
+        f32x16 acc[MB][NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.0f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            bool ok[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                ok[mb] = pv[mb] && (unsigned)(yh[mb] + dy) < (unsigned)H && (unsigned)(xw[mb] + dx) < (unsigned)W;
+            const uint4* ap = pc + (dy * W + dx) * kPix;
+            const uint4* wp = wl + (tap * CK * 2 + h2) * kNco + r;
+#pragma unroll
+            for (int s = 0; s < CK; ++s) {
+                bf16x8 wa[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wa[nb] = __builtin_bit_cast(bf16x8, wp[s * 2 * kNco + 32 * nb]);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    uint4 u = FBSMI_CONV_PROBE == 1 ? make_uint4(lane, tap, s, 0x3f803f80u) : ap[32 * mb * kPix + 2 * s];
+                    if (!ok[mb]) u = make_uint4(0u, 0u, 0u, 0u);
+                    const bf16x8 xa = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FBSMI_CONV_PROBE == 2 ? xa : wa[nb], xa, acc[mb][nb], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            if (!pv[mb]) continue;
+            __hip_bfloat16* yp = y + p[mb] * Cout + co0 + 4 * h2;
+            const float4* bp = reinterpret_cast<const float4*>(bias + co0 + 4 * h2);   // read only when bias != NULL
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (bias) b0 = bp[8 * nb + 2 * c];
+                    *reinterpret_cast<uint2*>(yp + 32 * nb + 8 * c) =
+                        make_uint2(pk_bf16(acc[mb][nb][4 * c] + b0.x, acc[mb][nb][4 * c + 1] + b0.y),
+                                   pk_bf16(acc[mb][nb][4 * c + 2] + b0.z, acc[mb][nb][4 * c + 3] + b0.w));
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // GroupNorm + modulation + SiLU.  One workgroup per image; a thread owns one aligned 8-channel vector slot
 // (always inside one group, since the group size is a multiple of 8) across a strided set of tokens:
 // pass 1 Welford-merges its vectors into (count, mean, M2), the slots of a group are merged through LDS
@@ -622,6 +743,59 @@ extern "C" int fbsmi_nn_qkv_linear_attention(const void* xn, const void* w, void
         default: k_qkv_linear_attention<8><<<(unsigned)B, 256, 0, st>>>(x_, w_, o_, n, heads); break;
     }
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
+    return FBSMI_OK;
+}
+
+extern "C" int fbsmi_nn_conv3x3(const void* x, const void* w, const float* bias, void* y, int64_t B, int32_t H, int32_t W,
+                                int32_t Cin, int32_t Cout, void* stream) {
+    if (!x || !w || !y || B < 0 || H < 1 || W < 1) return fail(FBSMI_ERR_ARG, "nn_conv3x3: bad arguments");
+    if ((Cin != 64 && Cin != 128) || Cout < 64 || Cout % 64 != 0)
+        return fail(FBSMI_ERR_UNSUPPORTED, "nn_conv3x3: Cin must be 64 or 128 and Cout a multiple of 64");
+    if (B == 0) return FBSMI_OK;
+    const long long npix = (long long)B * H * W;
+    const int ck = Cin / 16;
+    // 8 waves per workgroup when the staged range fits beside the weights (72 KB) in 160 KB of LDS, else 4; a wave multiplies
+    // 32 pixels (or 64: two accumulator rows sharing every weight fragment).  FBSMI_CONV_CFG=<waves><pixel blocks> overrides
+    // (diagnostic).
+    const int nco = ck == 4 ? 64 : 32;               // output channels per workgroup: 72 KB of weights either way
+    auto lds_of = [&](int nw, int mb) { return (size_t)16 * (9 * ck * 2 * nco + (size_t)(32 * mb * nw + 2 * W + 2) * (2 * ck + 1)); };
+    auto fits = [&](int nw, int mb) {
+        return lds_of(nw, mb) <= 160 * 1024 && (long long)(32 * mb * nw + 2 * W + 2) * 2 * ck <= (nw == 8 ? 10ll * 512 : 24ll * 256);
+    };
+    int nw = 8, mb = 1;      // measured (tools/bench_conv.py): 8 waves x 32 pixels beats 8 x 64 and both 4-wave shapes
+    if (!fits(nw, mb)) nw = 4;
+    if (const char* cfg = getenv("FBSMI_CONV_CFG")) { nw = cfg[0] - '0'; mb = cfg[1] - '0'; }
+    if ((nw != 4 && nw != 8) || (mb != 1 && mb != 2) || !fits(nw, mb))
+        return fail(FBSMI_ERR_UNSUPPORTED, "nn_conv3x3: image rows too wide for the staged range");
+    const size_t lds = lds_of(nw, mb);
+    const int tile = 32 * mb * nw;
+    const long long ntiles = (npix + tile - 1) / tile;
+    const long long cap = 256 * (long long)((160 * 1024) / lds);   // workgroups resident at once
+    const dim3 grid((unsigned)(ntiles < cap ? ntiles : cap), (unsigned)(Cout / nco));
+    hipStream_t st = (hipStream_t)stream;
+    const __hip_bfloat16 *x_ = (const __hip_bfloat16*)x, *w_ = (const __hip_bfloat16*)w;
+    __hip_bfloat16* y_ = (__hip_bfloat16*)y;
+    hipError_t e = hipSuccess;
+#define FBSMI_CONV_LAUNCH(CK_, NB_, NW_, MB_)                                                                              \
+    {                                                                                                                      \
+        e = hipFuncSetAttribute((const void*)k_conv3x3<CK_, NB_, NW_, MB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) k_conv3x3<CK_, NB_, NW_, MB_><<<grid, 64 * NW_, lds, st>>>(x_, w_, bias, y_, H, W, Cout, npix, ntiles); \
+    }
+    if (ck == 4) {
+        if (nw == 8 && mb == 2) FBSMI_CONV_LAUNCH(4, 2, 8, 2)
+        else if (nw == 8) FBSMI_CONV_LAUNCH(4, 2, 8, 1)
+        else if (mb == 2) FBSMI_CONV_LAUNCH(4, 2, 4, 2)
+        else FBSMI_CONV_LAUNCH(4, 2, 4, 1)
+    } else {
+        if (nw == 8 && mb == 2) FBSMI_CONV_LAUNCH(8, 1, 8, 2)
+        else if (nw == 8) FBSMI_CONV_LAUNCH(8, 1, 8, 1)
+        else if (mb == 2) FBSMI_CONV_LAUNCH(8, 1, 4, 2)
+        else FBSMI_CONV_LAUNCH(8, 1, 4, 1)
+    }
+#undef FBSMI_CONV_LAUNCH
+    if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
+    e = hipGetLastError();
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
     return FBSMI_OK;
 }

@@ -117,6 +117,8 @@ class WeightStandardizedConv(nn.Module):
                 if x.is_cuda and dt != torch.float32:
                     w = w.contiguous(memory_format=torch.channels_last)
             self._w_std, self._w_tag = w, tag
+        if self._w_std.dtype == torch.bfloat16 and _conv3x3_fusable(x, self._w_std, self.conv.stride, self.conv.padding):
+            return _conv3x3_hip(x, self._w_std, bias)
         return F.conv2d(x, self._w_std, bias, padding=self.conv.padding)
 
 
@@ -126,6 +128,47 @@ def _nchw_view(tok):
     reproducible run to run, which a sampler with explicit keys must be."""
     out = tok.permute(0, 3, 1, 2)
     return out.contiguous() if tok.dtype == torch.float32 else out
+
+
+def _conv3x3_fusable(x, weight, stride=(1, 1), padding=(1, 1)) -> bool:
+    """libfbsmi's 3 x 3 convolution takes bfloat16 channels_last inference activations with 64 or 128 input channels."""
+    if not (x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.bfloat16 and tuple(weight.shape[2:]) == (3, 3)
+            and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and weight.shape[1] in (64, 128)
+            and weight.shape[0] % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    # where it beats MIOpen (tools/bench_conv.py): every 64-channel input (1.6-2.3x), 128-channel inputs when the output is
+    # 64 channels wide or the rows are short enough for the 8-wave tile (1.1-2.4x); wide rows x wide outputs stay with MIOpen
+    return weight.shape[1] == 64 or weight.shape[0] == 64 or x.shape[3] <= 28
+
+
+def _conv3x3_hip(x, w16, bias):
+    """fbsmi_nn_conv3x3: w16 is the (Cout, Cin, 3, 3) weight in bfloat16, channels_last memory format."""
+    from . import _lib
+    B, Cin, H, W = x.shape
+    out = torch.empty((B, H, W, w16.shape[0]), dtype=torch.bfloat16, device=x.device)
+    _lib.call("fbsmi_nn_conv3x3", x.data_ptr(), w16.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+              B, H, W, Cin, w16.shape[0], torch.cuda.current_stream().cuda_stream)
+    return out.permute(0, 3, 1, 2)
+
+
+def _w16_of(conv: nn.Conv2d):
+    """The convolution's weight in bfloat16 / channels_last, converted once per weight version."""
+    w0 = conv.weight
+    tag = (w0._version, w0.data_ptr(), w0.device)
+    if getattr(conv, "_w16_tag", None) != tag:
+        conv._w16 = w0.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        conv._w16_tag = tag
+    return conv._w16
+
+
+def _conv1x1(x, weight):
+    """A 1x1 convolution without bias.  On channels_last inference activations it is a plain GEMM over the token-major view
+    (rows = pixels), which the BLAS library runs near the memory rate; MIOpen's implicit-GEMM kernel takes 2-3x as long for
+    the network's 128 -> 64 projections and zero-fills its output first."""
+    if (x.is_cuda and not torch.is_grad_enabled() and x.is_contiguous(memory_format=torch.channels_last)
+            and (x.dtype != torch.float32 or torch.is_autocast_enabled())):
+        return F.linear(x.permute(0, 2, 3, 1), weight.reshape(weight.shape[0], weight.shape[1])).permute(0, 3, 1, 2)
+    return F.conv2d(x, weight, None)
 
 
 def _gn_fusable(norm: nn.GroupNorm) -> bool:
@@ -178,7 +221,7 @@ class ResnetBlock(nn.Module):
             h = _gn_silu(self.conv_0(x, with_bias=False), self.norm_0, scale, shift, self.conv_0.conv.bias)
             rbias = None
             if self.res_conv is not None:     # its bias rides on the same kernel as the skip connection it feeds
-                x, rbias = F.conv2d(x, self.res_conv.weight, None), self.res_conv.bias
+                x, rbias = _conv1x1(x, self.res_conv.weight), self.res_conv.bias
             # ... and so is the skip connection: x + silu(norm_1(conv_1(h)))
             return _gn_silu(self.conv_1(h, with_bias=False), self.norm_1, None, None, self.conv_1.conv.bias, residual=x,
                             rbias=rbias)
@@ -232,7 +275,7 @@ class LinearAttention(nn.Module):
         B, C, H, W = x.shape
         if x.is_cuda and self.dim_head == 32 and not torch.is_grad_enabled():
             core = self._fused_qkv_core(x, B, H, W) if self._qkv_fusable(x) else self._fused_core(self.to_qkv(x), B, H, W)
-            y = F.conv2d(core, self.to_out.weight, None)
+            y = _conv1x1(core, self.to_out.weight)
             return self.to_out_norm(y, residual, xbias=self.to_out.bias)
         if residual is not None:
             return self.forward(x) + residual
@@ -325,6 +368,8 @@ def _conv_bias(conv: nn.Conv2d, x):
     by fbsmi_nn_bias_add instead of torch's broadcasting elementwise kernel."""
     if not (x.is_cuda and not torch.is_grad_enabled() and conv.bias is not None):
         return conv(x)
+    if _conv3x3_fusable(x, conv.weight, conv.stride, conv.padding):
+        return _conv3x3_hip(x, _w16_of(conv), conv.bias)
     return _add_bias(F.conv2d(x, conv.weight, None, conv.stride, conv.padding), conv.bias)
 
 

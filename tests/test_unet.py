@@ -202,6 +202,29 @@ def test_fused_qkv_linear_attention_on_the_matrix_cores(B, H, W, dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 28, 28, 64, 64), (2, 14, 14, 128, 128), (5, 7, 7, 64, 256), (1, 64, 64, 128, 64),
+                                           (2, 9, 13, 64, 64), (1, 1, 1, 64, 64), (300, 3, 2, 128, 64)])
+def test_conv3x3_on_the_matrix_cores(B, H, W, cin, cout):
+    """fbsmi_nn_conv3x3 against torch's convolution in float32 on the same bfloat16-rounded inputs and weights (the kernel
+    accumulates in float32 and rounds the result to bfloat16 once: tolerance = one bfloat16 rounding of the result plus
+    accumulation-order noise); image borders, tiles that straddle rows and images, a ragged last tile, the bias."""
+    from fbs_amd.unet import _conv3x3_hip
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B + cin + cout)
+    x = torch.randn(B, cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(cout, device=dev)
+    want = torch.nn.functional.conv2d(x.float(), w.float(), bias, padding=1)
+    got = _conv3x3_hip(x, w, bias).float()
+    assert got.shape == want.shape
+    tol = 2.0 ** -8 * want.abs() + 1e-3
+    assert bool(((got - want).abs() <= tol).all()), (got - want).abs().max().item()
+    got0 = _conv3x3_hip(x, w, None).float()
+    want0 = want - bias.view(1, -1, 1, 1)
+    assert bool(((got0 - want0).abs() <= 2.0 ** -8 * want0.abs() + 1e-3).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_bias_folds_and_pixel_shuffle_kernels(dtype):
     """fbsmi_nn_bias_add / fbsmi_nn_pixel_shuffle (+ bias) / the xbias of the channel LayerNorm against the torch ops they replace:
