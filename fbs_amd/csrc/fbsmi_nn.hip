@@ -311,7 +311,8 @@ __global__ void __launch_bounds__(256) k_qkv_linear_attention(const __hip_bfloat
 template <int CK, int NB, int NW, int MB>   // Cin = 16 * CK; 32 * NB output channels, 32 * MB pixels per wave, NW waves
 __global__ void __launch_bounds__(64 * NW) k_conv3x3(const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w,
                                                      const float* __restrict__ bias, __hip_bfloat16* __restrict__ y, int H, int W,
-                                                     int Cout, long long npix, long long ntiles) {
+                                                     int Cout, long long npix, long long ntiles, int xs, int ws, int ci0,
+                                                     int accumulate) {
     extern __shared__ uint4 lds[];
     constexpr int Cin = 16 * CK, kThreads = 64 * NW, kTile = 32 * MB * NW, kNco = 32 * NB;
     constexpr int kPix = 2 * CK + 1;                 // 16-byte chunks per staged pixel (the last one is padding)
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(64 * NW) k_conv3x3(const __hip_bfloat16* __res
     const int co0 = blockIdx.y * kNco;
     for (int i = threadIdx.x; i < 9 * CK * 2 * kNco; i += kThreads) {
         const int col = i % kNco, rest = i / kNco, hh = rest & 1, s = (rest >> 1) % CK, tap = (rest >> 1) / CK;
-        wl[i] = *reinterpret_cast<const uint4*>(w + ((size_t)(co0 + col) * 9 + tap) * Cin + 16 * s + 8 * hh);
+        wl[i] = *reinterpret_cast<const uint4*>(w + ((size_t)(co0 + col) * 9 + tap) * ws + ci0 + 16 * s + 8 * hh);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
     const int npatch = kTile + 2 * W + 2, nchunk = npatch * 2 * CK;
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(64 * NW) k_conv3x3(const __hip_bfloat16* __res
             const long long q = q0 + c / (2 * CK);
             uint4 u = make_uint4(0u, 0u, 0u, 0u);
             if (FBSMI_CONV_PROBE != 3 && c < nchunk && q >= 0 && q < npix)
-                u = *reinterpret_cast<const uint4*>(x + q * Cin + 8 * (c % (2 * CK)));
+                u = *reinterpret_cast<const uint4*>(x + q * xs + 8 * (c % (2 * CK)));
             stage[j] = u;
         }
     };
@@ -404,6 +405,13 @@ __global__ void __launch_bounds__(64 * NW) k_conv3x3(const __hip_bfloat16* __res
                 for (int c = 0; c < 4; ++c) {
                     float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (bias) b0 = bp[8 * nb + 2 * c];
+                    if (accumulate) {   // a later channel slice of the same convolution: add to what the earlier ones left
+                        const uint2 o = *reinterpret_cast<const uint2*>(yp + 32 * nb + 8 * c);
+                        b0.x += __uint_as_float(o.x << 16);
+                        b0.y += __uint_as_float(o.x & 0xffff0000u);
+                        b0.z += __uint_as_float(o.y << 16);
+                        b0.w += __uint_as_float(o.y & 0xffff0000u);
+                    }
                     *reinterpret_cast<uint2*>(yp + 32 * nb + 8 * c) =
                         make_uint2(pk_bf16(acc[mb][nb][4 * c] + b0.x, acc[mb][nb][4 * c + 1] + b0.y),
                                    pk_bf16(acc[mb][nb][4 * c + 2] + b0.z, acc[mb][nb][4 * c + 3] + b0.w));
@@ -747,9 +755,11 @@ extern "C" int fbsmi_nn_qkv_linear_attention(const void* xn, const void* w, void
     return FBSMI_OK;
 }
 
-extern "C" int fbsmi_nn_conv3x3(const void* x, const void* w, const float* bias, void* y, int64_t B, int32_t H, int32_t W,
-                                int32_t Cin, int32_t Cout, void* stream) {
-    if (!x || !w || !y || B < 0 || H < 1 || W < 1) return fail(FBSMI_ERR_ARG, "nn_conv3x3: bad arguments");
+extern "C" int fbsmi_nn_conv3x3(const void* x, int32_t xstride, const void* w, int32_t wstride, int32_t ci_off, const float* bias,
+                                void* y, int accumulate, int64_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream) {
+    if (!x || !w || !y || B < 0 || H < 1 || W < 1 || xstride < Cin || xstride % 8 != 0 || ci_off < 0 || ci_off % 8 != 0 ||
+        wstride < ci_off + Cin || wstride % 8 != 0)
+        return fail(FBSMI_ERR_ARG, "nn_conv3x3: bad arguments");
     if ((Cin != 64 && Cin != 128) || Cout < 64 || Cout % 64 != 0)
         return fail(FBSMI_ERR_UNSUPPORTED, "nn_conv3x3: Cin must be 64 or 128 and Cout a multiple of 64");
     if (B == 0) return FBSMI_OK;
@@ -780,7 +790,7 @@ extern "C" int fbsmi_nn_conv3x3(const void* x, const void* w, const float* bias,
 #define FBSMI_CONV_LAUNCH(CK_, NB_, NW_, MB_)                                                                              \
     {                                                                                                                      \
         e = hipFuncSetAttribute((const void*)k_conv3x3<CK_, NB_, NW_, MB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e == hipSuccess) k_conv3x3<CK_, NB_, NW_, MB_><<<grid, 64 * NW_, lds, st>>>(x_, w_, bias, y_, H, W, Cout, npix, ntiles); \
+        if (e == hipSuccess) k_conv3x3<CK_, NB_, NW_, MB_><<<grid, 64 * NW_, lds, st>>>(x_, w_, bias, y_, H, W, Cout, npix, ntiles, xstride, wstride, ci_off, accumulate); \
     }
     if (ck == 4) {
         if (nw == 8 && mb == 2) FBSMI_CONV_LAUNCH(4, 2, 8, 2)

@@ -104,22 +104,24 @@ class WeightStandardizedConv(nn.Module):
         return (w - mean) / torch.sqrt(var + 1e-5)
 
     def forward(self, x, with_bias: bool = True):
+        """x: an NCHW tensor, or a tuple of them standing for their concatenation along the channels."""
         bias = self.conv.bias if with_bias else None
         if torch.is_grad_enabled() or self.training:
-            return F.conv2d(x, self._standardised(), bias, padding=self.conv.padding)
+            return F.conv2d(_joined(x), self._standardised(), bias, padding=self.conv.padding)
         # inference: the weights are constants, standardise them once (per weight version, device and compute dtype)
         w0 = self.conv.weight
-        dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled()) else w0.dtype
+        x0 = _as_parts(x)[0]
+        dt = torch.get_autocast_dtype("cuda") if (x0.is_cuda and torch.is_autocast_enabled()) else w0.dtype
         tag = (w0._version, w0.data_ptr(), w0.device, dt)
         if getattr(self, "_w_tag", None) != tag:
             with torch.no_grad():
                 w = self._standardised().to(dt)
-                if x.is_cuda and dt != torch.float32:
+                if x0.is_cuda and dt != torch.float32:
                     w = w.contiguous(memory_format=torch.channels_last)
             self._w_std, self._w_tag = w, tag
         if self._w_std.dtype == torch.bfloat16 and _conv3x3_fusable(x, self._w_std, self.conv.stride, self.conv.padding):
             return _conv3x3_hip(x, self._w_std, bias)
-        return F.conv2d(x, self._w_std, bias, padding=self.conv.padding)
+        return F.conv2d(_joined(x), self._w_std, bias, padding=self.conv.padding)
 
 
 def _nchw_view(tok):
@@ -130,24 +132,62 @@ def _nchw_view(tok):
     return out.contiguous() if tok.dtype == torch.float32 else out
 
 
+def _as_parts(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x,)
+
+
+def _joined(x):
+    """A tuple of NCHW tensors stands for their concatenation along the channels (the skip connections of the up path)."""
+    return torch.cat(tuple(x), dim=1) if isinstance(x, (tuple, list)) else x
+
+
+def _channel_chunks(C: int):
+    """C (a multiple of 64) as slices of 128 and 64 channels: the widths libfbsmi's convolution multiplies at a time."""
+    out, c0 = [], 0
+    while C - c0 >= 128:
+        out.append((c0, 128))
+        c0 += 128
+    if C - c0 == 64:
+        out.append((c0, 64))
+    return out
+
+
 def _conv3x3_fusable(x, weight, stride=(1, 1), padding=(1, 1)) -> bool:
-    """libfbsmi's 3 x 3 convolution takes bfloat16 channels_last inference activations with 64 or 128 input channels."""
-    if not (x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.bfloat16 and tuple(weight.shape[2:]) == (3, 3)
-            and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and weight.shape[1] in (64, 128)
-            and weight.shape[0] % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last)):
+    """libfbsmi's 3 x 3 convolution takes bfloat16 channels_last inference activations whose channels come in slices of 64 or
+    128 -- one tensor or several (their concatenation is then never formed)."""
+    parts = _as_parts(x)
+    x0 = parts[0]
+    if not (x0.is_cuda and not torch.is_grad_enabled() and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1)
+            and tuple(padding) == (1, 1) and weight.shape[0] % 64 == 0 and sum(t.shape[1] for t in parts) == weight.shape[1]):
         return False
-    # where it beats MIOpen (tools/bench_conv.py): every 64-channel input (1.6-2.3x), 128-channel inputs when the output is
+    for t in parts:
+        if not (t.dtype == torch.bfloat16 and t.shape[1] % 64 == 0 and t.shape[0] == x0.shape[0] and t.shape[2:] == x0.shape[2:]
+                and t.is_contiguous(memory_format=torch.channels_last)):
+            return False
+    # where it beats MIOpen (tools/bench_conv.py): every 64-channel slice (1.6-2.3x), 128-channel slices when the output is
     # 64 channels wide or the rows are short enough for the 8-wave tile (1.1-2.4x); wide rows x wide outputs stay with MIOpen
-    return weight.shape[1] == 64 or weight.shape[0] == 64 or x.shape[3] <= 28
+    wide = any(t.shape[1] >= 128 for t in parts)
+    return (not wide) or weight.shape[0] == 64 or x0.shape[3] <= 28
 
 
 def _conv3x3_hip(x, w16, bias):
-    """fbsmi_nn_conv3x3: w16 is the (Cout, Cin, 3, 3) weight in bfloat16, channels_last memory format."""
+    """fbsmi_nn_conv3x3 over the channel slices of x (one tensor or a tuple standing for their concatenation); w16 is the
+    (Cout, Cin, 3, 3) weight in bfloat16, channels_last memory format."""
     from . import _lib
-    B, Cin, H, W = x.shape
-    out = torch.empty((B, H, W, w16.shape[0]), dtype=torch.bfloat16, device=x.device)
-    _lib.call("fbsmi_nn_conv3x3", x.data_ptr(), w16.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
-              B, H, W, Cin, w16.shape[0], torch.cuda.current_stream().cuda_stream)
+    parts = _as_parts(x)
+    B, _, H, W = parts[0].shape
+    cout, cin = w16.shape[0], w16.shape[1]
+    out = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=parts[0].device)
+    st = torch.cuda.current_stream().cuda_stream
+    first, off = True, 0
+    for t in parts:
+        C = t.shape[1]
+        for c0, width in _channel_chunks(C):
+            _lib.call("fbsmi_nn_conv3x3", t.data_ptr() + 2 * c0, C, w16.data_ptr(), cin, off + c0,
+                      bias.data_ptr() if (bias is not None and first) else None, out.data_ptr(), 0 if first else 1,
+                      B, H, W, width, cout, st)
+            first = False
+        off += C
     return out.permute(0, 3, 1, 2)
 
 
@@ -164,7 +204,24 @@ def _w16_of(conv: nn.Conv2d):
 def _conv1x1(x, weight):
     """A 1x1 convolution without bias.  On channels_last inference activations it is a plain GEMM over the token-major view
     (rows = pixels), which the BLAS library runs near the memory rate; MIOpen's implicit-GEMM kernel takes 2-3x as long for
-    the network's 128 -> 64 projections and zero-fills its output first."""
+    the network's 128 -> 64 projections and zero-fills its output first.  A tuple of inputs stands for their concatenation:
+    one GEMM per part, accumulated (addmm), the concatenation is never formed."""
+    if isinstance(x, (tuple, list)):
+        parts = tuple(x)
+        if all(t.is_cuda and t.is_contiguous(memory_format=torch.channels_last) and (t.dtype != torch.float32 or torch.is_autocast_enabled())
+               for t in parts) and not torch.is_grad_enabled():
+            w2 = weight.reshape(weight.shape[0], weight.shape[1])
+            out, off = None, 0
+            for t in parts:
+                C = t.shape[1]
+                tok = t.permute(0, 2, 3, 1)
+                if out is None:
+                    out = F.linear(tok, w2[:, off:off + C])
+                else:
+                    out = torch.addmm(out.reshape(-1, out.shape[-1]), tok.reshape(-1, C), w2[:, off:off + C].t()).view(out.shape)
+                off += C
+            return out.permute(0, 3, 1, 2)
+        x = torch.cat(parts, dim=1)
     if (x.is_cuda and not torch.is_grad_enabled() and x.is_contiguous(memory_format=torch.channels_last)
             and (x.dtype != torch.float32 or torch.is_autocast_enabled())):
         return F.linear(x.permute(0, 2, 3, 1), weight.reshape(weight.shape[0], weight.shape[1])).permute(0, 3, 1, 2)
@@ -213,9 +270,14 @@ class ResnetBlock(nn.Module):
         self.res_conv = nn.Conv2d(dim_in, dim, 1) if dim_in != dim else None
 
     def forward(self, x, time_emb):
-        if x.is_cuda and not torch.is_grad_enabled() and _gn_fusable(self.norm_0):
+        """x: an NCHW tensor, or (h, skip) standing for cat([h, skip], dim=1) -- the up path hands its skip connections
+        over unconcatenated so that the convolutions can take the two parts in turn."""
+        x0 = _as_parts(x)[0]
+        if isinstance(x, (tuple, list)) and (self.res_conv is None or x0.dtype != torch.bfloat16):
+            x = _joined(x)          # only the bfloat16 kernels take the parts in turn
+        if x0.is_cuda and not torch.is_grad_enabled() and _gn_fusable(self.norm_0):
             te = self.time_mlp(F.silu(time_emb)).float()
-            B = x.shape[0]
+            B = x0.shape[0]
             scale, shift = (p.expand(B, p.shape[1]).contiguous() for p in te.chunk(2, dim=1))
             # the convolution biases are added inside the normalisation kernel (one pass less over the activations)
             h = _gn_silu(self.conv_0(x, with_bias=False), self.norm_0, scale, shift, self.conv_0.conv.bias)
@@ -225,6 +287,7 @@ class ResnetBlock(nn.Module):
             # ... and so is the skip connection: x + silu(norm_1(conv_1(h)))
             return _gn_silu(self.conv_1(h, with_bias=False), self.norm_1, None, None, self.conv_1.conv.bias, residual=x,
                             rbias=rbias)
+        x = _joined(x)
         h = self.norm_0(self.conv_0(x))
         te = self.time_mlp(F.silu(time_emb))[:, :, None, None]
         scale, shift = te.chunk(2, dim=1)
@@ -496,13 +559,13 @@ class UNet(nn.Module):
         h = _conv_bias(self.down_last_conv, h)
         h = self.mid_res_1(self.mid_attn(self.mid_res_0(h, emb)), emb)
         for ind in reversed(range(nres)):
-            h = self.up_res_0[str(ind)](torch.cat([h, hs.pop()], dim=1), emb)
-            h = self.up_res_1[str(ind)](torch.cat([h, hs.pop()], dim=1), emb)
+            h = self.up_res_0[str(ind)]((h, hs.pop()), emb)      # (h, skip) = cat([h, skip], dim=1), formed only if needed
+            h = self.up_res_1[str(ind)]((h, hs.pop()), emb)
             h = self.up_attn[str(ind)](h)
             if ind > 0:
                 h = self.up_sample[str(ind)](h)
         h = _conv_bias(self.up_last_conv, h)
-        out = self.final_conv(self.final_res(torch.cat([h, hs.pop()], dim=1), emb))
+        out = self.final_conv(self.final_res((h, hs.pop()), emb))
         out = out.permute(0, 2, 3, 1)
         return out[0] if (squeeze or B == 1) else out
 

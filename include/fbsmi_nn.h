@@ -26,11 +26,16 @@ int fbsmi_nn_linear_attention(const void* qkv, void* out, int dtype, int64_t B, 
 int fbsmi_nn_qkv_linear_attention(const void* xn, const void* w, void* out, int64_t B, int32_t n, int32_t C, int32_t heads,
                                   int32_t dim_head, void* stream);
 
-/* 3 x 3 convolution, stride 1, zero padding 1, bfloat16 on the matrix cores (float32 accumulation), for the network's narrow
- * layers: x (B, H, W, Cin) token-major, w (Cout, 3, 3, Cin) (a torch weight in channels_last memory format), bias (Cout)
- * float32 or NULL, y (B, H, W, Cout).  Cin in {64, 128}, Cout a multiple of 64. */
-int fbsmi_nn_conv3x3(const void* x, const void* w, const float* bias, void* y, int64_t B, int32_t H, int32_t W, int32_t Cin,
-                     int32_t Cout, void* stream);
+/* 3 x 3 convolution, stride 1, zero padding 1, bfloat16 on the matrix cores (float32 accumulation), for the network's layers
+ * whose input comes in slices of 64 or 128 channels:
+ *   y[b, i, j, :] (+)= bias + sum over taps and the Cin channels of this slice of w[:, tap, ci_off + c] x[b, i + di, j + dj, c]
+ * x: (B, H, W, .) token-major with `xstride` elements between pixels (a channel slice of a wider tensor: point x at the
+ * slice's first channel), w: (Cout, 3, 3, wstride) (a torch weight in channels_last memory format; wstride = its full input
+ * width, ci_off = where this slice's channels start), bias (Cout) float32 or NULL, y (B, H, W, Cout); accumulate != 0 adds to
+ * y instead of overwriting it (the later slices of a wide or concatenated input: conv(cat(a, b)) = conv_a(a) + conv_b(b), so
+ * the concatenation is never formed).  Cin in {64, 128}, Cout a multiple of 64. */
+int fbsmi_nn_conv3x3(const void* x, int32_t xstride, const void* w, int32_t wstride, int32_t ci_off, const float* bias, void* y,
+                     int accumulate, int64_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
 
 /* GroupNorm (biased variance, eps) + per-image channel modulation + SiLU in one pass over the activations --
  * the two normalisation sites of ResnetBlock (fbs/nn/unet.py:127-172):

@@ -225,6 +225,30 @@ def test_conv3x3_on_the_matrix_cores(B, H, W, cin, cout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,parts,cout", [(3, 14, 14, (128, 64), 128), (2, 7, 7, (256, 128), 256), (2, 28, 28, (64, 64), 64),
+                                             (1, 9, 5, (192,), 64), (2, 6, 6, (256,), 128)])
+def test_conv3x3_over_channel_slices_and_unconcatenated_inputs(B, H, W, parts, cout):
+    """conv(cat(a, b)) = conv_a(a) + conv_b(b): the kernel takes the inputs' channel slices (128 / 64 wide) in turn and
+    accumulates in the output (rounded to bfloat16 between slices: one more rounding per slice in the tolerance)."""
+    from fbs_amd.unet import _conv3x3_fusable, _conv3x3_hip
+    dev = torch.device("cuda:0")
+    torch.manual_seed(sum(parts) + cout)
+    xs = tuple(torch.randn(B, c, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for c in parts)
+    cin = sum(parts)
+    w = (torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(cout, device=dev)
+    with torch.no_grad():
+        assert _conv3x3_fusable(xs if len(xs) > 1 else xs[0], w)
+        got = _conv3x3_hip(xs if len(xs) > 1 else xs[0], w, bias).float()
+    want = torch.nn.functional.conv2d(torch.cat([t.float() for t in xs], dim=1), w.float(), bias, padding=1)
+    # every slice but the last leaves a bfloat16-rounded PARTIAL sum, whose size is that of the whole result's scale, not of
+    # the element's final value: one rounding (2^-9 relative) of a partial of up to ~the largest output per extra slice
+    nslices = sum((c + 127) // 128 for c in parts)
+    tol = 2.0 ** -8 * want.abs() + (nslices - 1) * 2.0 ** -9 * 2.0 * want.abs().max() + 4e-3
+    assert got.shape == want.shape and bool(((got - want).abs() <= tol).all()), (got - want).abs().max().item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_bias_folds_and_pixel_shuffle_kernels(dtype):
     """fbsmi_nn_bias_add / fbsmi_nn_pixel_shuffle (+ bias) / the xbias of the channel LayerNorm against the torch ops they replace:
