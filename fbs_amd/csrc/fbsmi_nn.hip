@@ -480,8 +480,7 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
     // ---- pass 1
     float cnt = 0.0f, mean = 0.0f, M2 = 0.0f;
     if (tl < lanes) {
-        for (int tok = tl; tok < n; tok += lanes) {
-            Vec8 v = ld8(xb + (size_t)tok * C);
+        auto merge = [&](Vec8 v) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v.v[i] += xb8[i];
             float s = 0.0f;
@@ -495,7 +494,14 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
             mean += dlt * (8.0f / nn);
             M2 += q + dlt * dlt * (cnt * 8.0f / nn);
             cnt = nn;
+        };
+        int tok = tl;
+        for (; tok + 3 * lanes < n; tok += 4 * lanes) {   // four vectors in flight per thread (one workgroup streams an image)
+            const Vec8 v0 = ld8(xb + (size_t)tok * C), v1 = ld8(xb + (size_t)(tok + lanes) * C),
+                       v2 = ld8(xb + (size_t)(tok + 2 * lanes) * C), v3 = ld8(xb + (size_t)(tok + 3 * lanes) * C);
+            merge(v0); merge(v1); merge(v2); merge(v3);
         }
+        for (; tok < n; tok += lanes) merge(ld8(xb + (size_t)tok * C));
     }
     sN[t] = cnt;
     sMean[t] = mean;
@@ -535,19 +541,32 @@ __global__ void __launch_bounds__(256) k_groupnorm_silu(const T* __restrict__ x,
         float rb8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) rb8[i] = (rb && rbias) ? rbias[slot * 8 + i] : 0.0f;
-        for (int tok = tl; tok < n; tok += lanes) {
-            Vec8 v = ld8(xb + (size_t)tok * C);
+        auto apply = [&](int tok, Vec8 v, const Vec8& r) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float z = fmaf(v.v[i], a[i], c[i]);
                 v.v[i] = z / (1.0f + expf(-z));
             }
-            if (rb) {
-                const Vec8 r = ld8(rb + (size_t)tok * C);
+            if (rb)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v.v[i] += r.v[i] + rb8[i];
-            }
             st8(yb + (size_t)tok * C, v);
+        };
+        int tok = tl;
+        for (; tok + 3 * lanes < n; tok += 4 * lanes) {
+            Vec8 v[4], r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = ld8(xb + (size_t)(tok + j * lanes) * C);
+                if (rb) r[j] = ld8(rb + (size_t)(tok + j * lanes) * C);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) apply(tok + j * lanes, v[j], r[j]);
+        }
+        for (; tok < n; tok += lanes) {
+            Vec8 r;
+            if (rb) r = ld8(rb + (size_t)tok * C);
+            apply(tok, ld8(xb + (size_t)tok * C), r);
         }
     }
 }
