@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(64 * NW) k_conv3x3(const __hip_bfloat16* __res
     constexpr int Cin = 16 * CK, kThreads = 64 * NW, kTile = 32 * MB * NW, kNco = 32 * NB;
     constexpr int kPix = 2 * CK + 1;                 // 16-byte chunks per staged pixel (the last one is padding)
     uint4* wl = lds;                                 // [9][CK][2][kNco]
-    uint4* patch = lds + 9 * CK * 2 * kNco;          // [kTile + 2 W + 2][kPix]
+    uint4* patch = lds + 9 * CK * 2 * kNco;          // [kTile + 2 W + 2 (+ 1 zero pixel)][kPix]
     const int co0 = blockIdx.y * kNco;
     for (int i = threadIdx.x; i < 9 * CK * 2 * kNco; i += kThreads) {
         const int col = i % kNco, rest = i / kNco, hh = rest & 1, s = (rest >> 1) % CK, tap = (rest >> 1) / CK;
@@ -326,42 +326,58 @@ __global__ void __launch_bounds__(64 * NW) k_conv3x3(const __hip_bfloat16* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
     const int npatch = kTile + 2 * W + 2, nchunk = npatch * 2 * CK;
     constexpr int kMaxPer = NW == 8 ? 10 : 24;       // staged chunks per thread (host: nchunk <= kMaxPer * kThreads)
+    // what does not change from tile to tile is worked out once: which chunk of the staged range a thread fetches (pixel
+    // offset, element offset, LDS slot); pixel indices fit 32 bits (host check)
+    int fdq[kMaxPer], foff[kMaxPer], fslot[kMaxPer];
+#pragma unroll
+    for (int j = 0; j < kMaxPer; ++j) {
+        const int c = threadIdx.x + j * kThreads;
+        const bool live = c < nchunk;
+        fdq[j] = live ? c / (2 * CK) : -0x40000000;  // dead slots fail the range test below
+        foff[j] = (c / (2 * CK)) * xs + 8 * (c % (2 * CK));
+        fslot[j] = live ? (c / (2 * CK)) * kPix + c % (2 * CK) : -1;
+    }
+    const int np = (int)npix;
     uint4 stage[kMaxPer];
-    auto fetch = [&](long long t) {                  // tile t's input chunks -> registers (zeros outside the batch)
-        const long long q0 = t * kTile - W - 1;
+    auto fetch = [&](int t) {                        // tile t's input chunks -> registers (zeros outside the batch)
+        const int q0 = t * kTile - W - 1;
+        const __hip_bfloat16* xq = x + (long long)q0 * xs;   // wave-uniform base, 32-bit lane offsets
 #pragma unroll
         for (int j = 0; j < kMaxPer; ++j) {
-            const int c = threadIdx.x + j * kThreads;
-            const long long q = q0 + c / (2 * CK);
             uint4 u = make_uint4(0u, 0u, 0u, 0u);
-            if (FBSMI_CONV_PROBE != 3 && c < nchunk && q >= 0 && q < npix)
-                u = *reinterpret_cast<const uint4*>(x + q * xs + 8 * (c % (2 * CK)));
+            if (FBSMI_CONV_PROBE != 3 && (unsigned)(q0 + fdq[j]) < (unsigned)np) u = *reinterpret_cast<const uint4*>(xq + foff[j]);
             stage[j] = u;
         }
     };
-    long long t = blockIdx.x;
-    if (t < ntiles) fetch(t);
-    for (; t < ntiles; t += gridDim.x) {
-        __syncthreads();                             // the previous tile's fragment reads are done (and the weights are in)
+    // a tap whose neighbour is outside the image reads an all-zero pixel instead (one more slot behind the staged range)
+    uint4* zero_px = patch + npatch * kPix;
+    if (threadIdx.x < 2 * CK) zero_px[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    int t = blockIdx.x;
+    const int nt = (int)ntiles, tstep = gridDim.x;
+    if (t < nt) fetch(t);
+    for (; t < nt; t += tstep) {
+        __syncthreads();                             // the previous tile's reads are done (and the weights are in)
 #pragma unroll
-        for (int j = 0; j < kMaxPer; ++j) {
-            const int c = threadIdx.x + j * kThreads;
-            if (c < nchunk) patch[(c / (2 * CK)) * kPix + c % (2 * CK)] = stage[j];
-        }
+        for (int j = 0; j < kMaxPer; ++j)
+            if (fslot[j] >= 0) patch[fslot[j]] = stage[j];
         __syncthreads();
-        if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
-        long long p[MB];
-        bool pv[MB];
-        int xw[MB], yh[MB];
+        if (t + tstep < nt) fetch(t + tstep);
+        const uint4* pcs[MB][9];                     // where this lane's fragments of tap (dy, dx) start: its neighbour, or zeros
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-            p[mb] = t * kTile + 32 * (MB * wave + mb) + r;
-            pv[mb] = p[mb] < npix;
-            const long long pp = pv[mb] ? p[mb] : npix - 1;
-            xw[mb] = (int)(pp % W);
-            yh[mb] = (int)((pp / W) % H);
+            const int p = t * kTile + 32 * (MB * wave + mb) + r;
+            const bool pv = p < np;
+            const unsigned pp = pv ? p : np - 1;
+            const unsigned prow = pp / (unsigned)W;
+            const int xw = (int)(pp - prow * W), yh = (int)(prow % (unsigned)H);
+            const uint4* pc = patch + (32 * (MB * wave + mb) + r + W + 1) * kPix + h2;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const bool ok = pv && (unsigned)(yh + dy) < (unsigned)H && (unsigned)(xw + dx) < (unsigned)W;
+                pcs[mb][tap] = ok ? pc + (dy * W + dx) * kPix : zero_px + h2;
+            }
         }
-        const uint4* pc = patch + (32 * MB * wave + r + W + 1) * kPix + h2;   // this lane's first centre pixel
         f32x16 acc[MB][NB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
@@ -369,53 +385,84 @@ __global__ void __launch_bounds__(64 * NW) k_conv3x3(const __hip_bfloat16* __res
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.0f;
+        // k-steps (tap, s) in order; the fragments of step i + 2 are requested before the products of step i are issued
+        // (scheduling barriers: left alone, the compiler reads each fragment right before its use and every pair of products
+        // waits out an LDS round trip)
+        constexpr int kSteps = 9 * CK, kAhead = 2;
+        uint4 fa[kAhead + 1][MB], fw[kAhead + 1][NB];
+        auto request = [&](int i, uint4 (&xa)[MB], uint4 (&wa)[NB]) {
+            const int tap = i / CK, s = i % CK;
+            const uint4* wp = wl + ((tap * CK + s) * 2 + h2) * kNco + r;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            bool ok[MB];
+            for (int mb = 0; mb < MB; ++mb) xa[mb] = FBSMI_CONV_PROBE == 1 ? make_uint4(lane, tap, s, 0x3f803f80u) : pcs[mb][tap][2 * s];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-                ok[mb] = pv[mb] && (unsigned)(yh[mb] + dy) < (unsigned)H && (unsigned)(xw[mb] + dx) < (unsigned)W;
-            const uint4* ap = pc + (dy * W + dx) * kPix;
-            const uint4* wp = wl + (tap * CK * 2 + h2) * kNco + r;
+            for (int nb = 0; nb < NB; ++nb) wa[nb] = wp[32 * nb];
+        };
 #pragma unroll
-            for (int s = 0; s < CK; ++s) {
-                bf16x8 wa[NB];
+        for (int i = 0; i < kAhead; ++i) request(i, fa[i], fw[i]);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) wa[nb] = __builtin_bit_cast(bf16x8, wp[s * 2 * kNco + 32 * nb]);
+        for (int i = 0; i < kSteps; ++i) {
+            if (i + kAhead < kSteps) request(i + kAhead, fa[(i + kAhead) % (kAhead + 1)], fw[(i + kAhead) % (kAhead + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    uint4 u = FBSMI_CONV_PROBE == 1 ? make_uint4(lane, tap, s, 0x3f803f80u) : ap[32 * mb * kPix + 2 * s];
-                    if (!ok[mb]) u = make_uint4(0u, 0u, 0u, 0u);
-                    const bf16x8 xa = __builtin_bit_cast(bf16x8, u);
+            for (int mb = 0; mb < MB; ++mb) {
+                const bf16x8 xa = __builtin_bit_cast(bf16x8, fa[i % (kAhead + 1)][mb]);
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FBSMI_CONV_PROBE == 2 ? xa : wa[nb], xa, acc[mb][nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8 wa = FBSMI_CONV_PROBE == 2 ? xa : __builtin_bit_cast(bf16x8, fw[i % (kAhead + 1)][nb]);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xa, acc[mb][nb], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- the tile's results leave as whole rows.  In the accumulators a lane holds 4-channel groups of ITS pixel, and
+        // stored from there every lane of a store instruction writes 8 bytes of a different row (a write request each: that
+        // was half of this kernel's time).  Instead: the lane halves swap the odd / even groups (v_permlane32_swap) so a
+        // lane owns 16-byte chunks, the wave parks its 32 x (32 NB) tile in LDS -- in the staged input's memory, once every
+        // wave is done reading it -- and reads it back with consecutive lanes along the rows.
+        __syncthreads();
+        constexpr int kRow = 2 * kNco + 16;                     // bytes of a parked row (one pad chunk)
+        constexpr int kCpr = kNco / 8;                          // 16-byte chunks per row
+        char* park = reinterpret_cast<char*>(patch) + (size_t)wave * MB * 32 * kRow;
+        const float4* bp = reinterpret_cast<const float4*>(bias + co0 + 4 * h2);   // read only when bias != NULL
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-            if (!pv[mb]) continue;
-            __hip_bfloat16* yp = y + p[mb] * Cout + co0 + 4 * h2;
-            const float4* bp = reinterpret_cast<const float4*>(bias + co0 + 4 * h2);   // read only when bias != NULL
+            char* pk = park + (size_t)mb * 32 * kRow;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (bias) b0 = bp[8 * nb + 2 * c];
-                    if (accumulate) {   // a later channel slice of the same convolution: add to what the earlier ones left
-                        const uint2 o = *reinterpret_cast<const uint2*>(yp + 32 * nb + 8 * c);
-                        b0.x += __uint_as_float(o.x << 16);
-                        b0.y += __uint_as_float(o.x & 0xffff0000u);
-                        b0.z += __uint_as_float(o.y << 16);
-                        b0.w += __uint_as_float(o.y & 0xffff0000u);
-                    }
-                    *reinterpret_cast<uint2*>(yp + 32 * nb + 8 * c) =
-                        make_uint2(pk_bf16(acc[mb][nb][4 * c] + b0.x, acc[mb][nb][4 * c + 1] + b0.y),
-                                   pk_bf16(acc[mb][nb][4 * c + 2] + b0.z, acc[mb][nb][4 * c + 3] + b0.w));
+                for (int j = 0; j < 2; ++j) {
+                    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+                    if (bias) { b0 = bp[8 * nb + 4 * j]; b1 = bp[8 * nb + 4 * j + 2]; }
+                    const f32x16& A = acc[mb][nb];
+                    const unsigned p0x = pk_bf16(A[8 * j] + b0.x, A[8 * j + 1] + b0.y), p0y = pk_bf16(A[8 * j + 2] + b0.z, A[8 * j + 3] + b0.w);
+                    const unsigned p1x = pk_bf16(A[8 * j + 4] + b1.x, A[8 * j + 5] + b1.y), p1y = pk_bf16(A[8 * j + 6] + b1.z, A[8 * j + 7] + b1.w);
+                    const auto rx = __builtin_amdgcn_permlane32_swap(p0x, p1x, false, false);
+                    const auto ry = __builtin_amdgcn_permlane32_swap(p0y, p1y, false, false);
+                    *reinterpret_cast<uint4*>(pk + r * kRow + nb * 64 + (2 * j + h2) * 16) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
                 }
+            // rows back out: lane l takes chunk l % kCpr of row l / kCpr (+ 64 / kCpr per round)
+            const long long prow0 = (long long)t * kTile + 32 * (MB * wave + mb);
+#pragma unroll
+            for (int rd = 0; rd < kCpr / 2; ++rd) {
+                const int row = lane / kCpr + rd * (64 / kCpr), ch = lane % kCpr;
+                uint4 u = *reinterpret_cast<const uint4*>(pk + row * kRow + ch * 16);
+                const long long pr = prow0 + row;
+                if (pr < npix) {
+                    uint4* dst = reinterpret_cast<uint4*>(y + pr * Cout + co0 + 8 * ch);
+                    if (accumulate) {   // a later channel slice of the same convolution: add to what the earlier ones left
+                        const uint4 o = *dst;
+                        const unsigned ow[4] = {o.x, o.y, o.z, o.w}, uw[4] = {u.x, u.y, u.z, u.w};
+                        unsigned rw[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            rw[k] = pk_bf16(__uint_as_float(ow[k] << 16) + __uint_as_float(uw[k] << 16),
+                                            __uint_as_float(ow[k] & 0xffff0000u) + __uint_as_float(uw[k] & 0xffff0000u));
+                        u = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+                    }
+                    *dst = u;
+                }
+            }
         }
     }
 }
@@ -783,12 +830,13 @@ extern "C" int fbsmi_nn_conv3x3(const void* x, int32_t xstride, const void* w, i
         return fail(FBSMI_ERR_UNSUPPORTED, "nn_conv3x3: Cin must be 64 or 128 and Cout a multiple of 64");
     if (B == 0) return FBSMI_OK;
     const long long npix = (long long)B * H * W;
+    if (npix > 0x3fffffff) return fail(FBSMI_ERR_UNSUPPORTED, "nn_conv3x3: more than 2^30 pixels per call");
     const int ck = Cin / 16;
     // 8 waves per workgroup when the staged range fits beside the weights (72 KB) in 160 KB of LDS, else 4; a wave multiplies
     // 32 pixels (or 64: two accumulator rows sharing every weight fragment).  FBSMI_CONV_CFG=<waves><pixel blocks> overrides
     // (diagnostic).
     const int nco = ck == 4 ? 64 : 32;               // output channels per workgroup: 72 KB of weights either way
-    auto lds_of = [&](int nw, int mb) { return (size_t)16 * (9 * ck * 2 * nco + (size_t)(32 * mb * nw + 2 * W + 2) * (2 * ck + 1)); };
+    auto lds_of = [&](int nw, int mb) { return (size_t)16 * (9 * ck * 2 * nco + (size_t)(32 * mb * nw + 2 * W + 3) * (2 * ck + 1)); };
     auto fits = [&](int nw, int mb) {
         return lds_of(nw, mb) <= 160 * 1024 && (long long)(32 * mb * nw + 2 * W + 2) * 2 * ck <= (nw == 8 ? 10ll * 512 : 24ll * 256);
     };
