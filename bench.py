@@ -9,9 +9,10 @@ device; the whole sweep is a hipGraph replay (no host work inside the timed regi
 graph launches).
 
 The batch of one step is `--nchains` independent chains (default 4 = the reference driver's default,
-experiments/toy/gp_gibbs.py:25, which vmaps gibbs_kernel over chains :172-173): every kernel
-launch advances all chains of the batch, exactly as the reference's single XLA program does.  The
-single-chain rate is measured too and reported in `single_chain`.
+experiments/toy/gp_gibbs.py:25, which vmaps gibbs_kernel over chains :172-173).  A batch of four or more chains is
+driven as two groups of half the chains, each group's launches on its own stream (fbs_amd.LGSweep): the step kernels are
+latency-bound, the groups' launches interleave (+6 % at 4 chains, +18-27 % at 16-32; FBSMI_CHAIN_GROUPS=1 keeps one
+group) -- same results bit for bit.  The single-chain rate is measured too and reported in `single_chain`.
 
 Multi-GPU (--gpus N under torch.distributed.run): every GPU runs its own batch of chains -- the
 reference's own parallel axes (nchains, --id replicas) -- no data-path collective, weak scaling: that is `value`.
@@ -310,22 +311,34 @@ def main():
     out = None
     if rank == 0:
         # ---- per-kernel durations with HIP events on the launch stream (untimed extra sweeps) ----
-        sweep.profile(True)
-        sweep.chain(key, x0, y0, bs, 2, keep=False, use_graph=False)
+        # A batch of >= 4 chains runs as two groups of half the chains on two streams (fbs_amd.LGSweep): the launches that
+        # exist are one group's, so one group is profiled, alone, and bytes per launch count ITS chains.
+        ph = sweep.children[0] if sweep.children else sweep
+        Cp = ph.C
+        kp, xp, bp_ = fbs_amd.PRNGKey(11), np.zeros((Cp, 1), np.float32), np.zeros((Cp, T + 1), np.int32)
+        kp, xp, bp_, _ = ph.chain(kp, xp, y0, bp_, 2, keep=False)
+        torch.cuda.synchronize(dev)
+        tp0 = time.perf_counter()
+        nrep_p = max(4, args.steps // 2)
+        kp, xp, bp_, _ = ph.chain(kp, xp, y0, bp_, nrep_p, keep=False)
+        torch.cuda.synchronize(dev)
+        group_step_us = (time.perf_counter() - tp0) / nrep_p * 1e6 / T     # graph-timed step of one group running alone
+        ph.profile(True)
+        ph.chain(kp, xp, y0, bp_, 2, keep=False, use_graph=False)
         torch.cuda.synchronize(dev)
         kern = {}
         for i, name in enumerate(KERNELS):
-            us, n = sweep.kernel_us(i)
+            us, n = ph.kernel_us(i)
             if n:
                 kern[name] = {"avg_us": us, "launches": n}
-        sweep.profile(False)
+        ph.profile(False)
         bpp = algorithmic_bytes_per_particle(br.du)
-        prop_bytes = bpp["prop"] * N * C
+        prop_bytes = bpp["prop"] * N * Cp
         # A hipEvent pair brackets each launch, so every per-kernel figure carries the same additive
         # event overhead c.  The step kernels tile a step of the graph-timed region, hence
         # c = (sum of their event figures - graph-timed step) / their number; durations below are net of c.
         raw = {k: v["avg_us"] for k, v in kern.items()}
-        step_us = ms_per_step * 1e3 / T
+        step_us = group_step_us
         c_ev = max(0.0, (sum(raw.values()) - step_us) / float(len(raw)))
         net = {k: max(v - c_ev, 1e-3) for k, v in raw.items()}
         prop_us = net["prop"]
@@ -343,7 +356,8 @@ def main():
                 except Exception:
                     break
                 wl = tj.get("workload", {})
-                if tj.get("kernel", "").startswith(kname) and wl == {"nparticles": N, "nsteps": T, "nchains": C}:
+                if tj.get("kernel", "").startswith(kname) and wl == {"nparticles": N, "nsteps": T, "nchains": C} and \
+                        tj.get("chains_per_launch", C) == Cp:
                     insts = tj.get("valu_insts_per_launch")
                     prof = {"file": os.path.relpath(tpath, ROOT), "kernel": tj.get("kernel"), "workload": wl,
                             "hbm_bytes_per_launch": tj.get("bytes_per_launch"),
@@ -360,15 +374,19 @@ def main():
                     "limiter": "vector-instruction issue and dependent round trips (the per-step working set is cache resident): "
                                "the HBM fraction is reported because SURVEY 8(d) assigns this path the HBM roof, not because "
                                "the kernel is near it",
-                    "bytes_per_launch": prop_bytes, "avg_launch_us": prop_us,
-                    "timing": "hipEvent pairs around each launch on the launch stream, net of the event overhead "
-                              "calibrated against the graph-timed step (see bench.py)",
+                    "bytes_per_launch": prop_bytes, "avg_launch_us": prop_us, "chains_per_launch": Cp,
+                    "chain_groups": len(sweep.children) if sweep.children else 1,
+                    "timing": "hipEvent pairs around each launch on the launch stream of ONE chain group running alone, net of "
+                              "the event overhead calibrated against that group's graph-timed step (see bench.py)",
                     "event_overhead_us": c_ev, "raw_event_us": raw, "kernels_us": net,
                     "whole_sweep_GBps": bpp["step"] * float(N) * T * C / (ms_per_step * 1e-3) / 1e9,
                     "whole_step_frac": bpp["step"] * float(N) * T * C / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
                     "launches_per_step": len(kern),
                     "note": "working set per step is a few MB (cache-resident) and the kernel is latency- then "
-                            "VALU-bound (in-kernel Threefry + erf_inv), not HBM-bound: see DESIGN.md"}
+                            "VALU-bound (in-kernel Threefry + erf_inv), not HBM-bound: see DESIGN.md.  With chain_groups = 2 the "
+                            "timed sweeps keep TWO such launches in flight (one per group, each carrying chains_per_launch chains): "
+                            "kernel durations then add up to more than the wall clock, and achieved / frac describe one launch "
+                            "running alone"}
         single = None
         if C != 1 and not args.no_single_chain:
             sw1 = br.sweep_handle(N, True, False, nchains=1)

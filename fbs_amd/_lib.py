@@ -92,6 +92,8 @@ SIGNATURES = {
     "fbsmi_lg_sweep_destroy": (None, [_vp]),
     "fbsmi_lg_gibbs_sweep": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "fbsmi_lg_gibbs_chain": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_int, _vp]),
+    "fbsmi_lg_sweep_set_group": (C.c_int, [_vp, _i32, _i32]),
+    "fbsmi_lg_gibbs_chain_groups": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, C.c_int, _vp]),
     "fbsmi_lg_sweep_view": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(_i64), _vp]),
     "fbsmi_lg_filter_create": (C.c_int, [C.POINTER(LGModelStruct), _i32, C.c_int, C.c_int, C.c_int, _i32, C.POINTER(_vp)]),
     "fbsmi_lg_filter_destroy": (None, [_vp]),

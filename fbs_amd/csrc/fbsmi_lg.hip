@@ -49,6 +49,7 @@ constexpr int kNumProfKernels = 3; // norm, cdf, prop
 
 struct LgDev {
     int C;           // independent chains batched in every launch (blockIdx.y): jax.vmap over chains
+    int Ctot, c0;    // this handle drives chains c0 .. c0 + C - 1 of a batch of Ctot (fbsmi_lg_sweep_set_group; default C, 0)
     int N;           // rows of the particle system (nparticles, +1 when explicit_final)
     int nparticles;
     int du, dv, D, T;
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_keys(LgDev dd, int chain) {
             // chains with split(subkey, C)[c] (experiments/toy/gp_gibbs.py:183-185)
             uint32_t b0, b1;
             split_at(d.key[0], d.key[1], 2, 1, b0, b1);
-            if (d.C > 1) split_at(b0, b1, d.C, blockIdx.y, k0, k1);
+            if (d.Ctot > 1) split_at(b0, b1, d.Ctot, d.c0 + blockIdx.y, k0, k1);
             else { k0 = b0; k1 = b1; }
         }
         uint32_t f0, f1, c0, c1;
@@ -2661,7 +2662,7 @@ __global__ void k_lg_advance(LgDev dd) {
     for (int r = threadIdx.x; r < d.du; r += blockDim.x) {
         const float x = d.x0n[r];
         d.x0[r] = x;
-        if (x0s) x0s[((size_t)cnt * d.C + c) * d.du + r] = x;
+        if (x0s) x0s[((size_t)cnt * d.Ctot + d.c0 + c) * d.du + r] = x;
     }
     for (int k = threadIdx.x; k <= d.T; k += blockDim.x) d.bs[k] = d.bsn[k];
 }
@@ -2966,6 +2967,8 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     if (!s) return fail(FBSMI_ERR_ARG, "out of host memory");
     LgDev& d = s->d;
     d.C = nchains;
+    d.Ctot = nchains;
+    d.c0 = 0;
     d.nparticles = nparticles;
     d.N = explicit_final ? nparticles + 1 : nparticles;
     d.du = m->du;
@@ -3160,10 +3163,10 @@ int fbsmi_lg_gibbs_sweep(fbsmi_lg_sweep* s, const uint32_t* keys, const float* x
     return FBSMI_OK;
 }
 
-int fbsmi_lg_gibbs_chain(fbsmi_lg_sweep* s, uint32_t* key, float* x0, const float* y0, int32_t* bs_star,
-                         int32_t nsweeps, float* x0s, int use_graph, void* stream) {
-    if (!s || !key || !x0 || !y0 || !bs_star || nsweeps < 0) return fail(FBSMI_ERR_ARG, "lg_gibbs_chain: bad arguments");
-    hipStream_t ust = (hipStream_t)stream;
+namespace {
+// inputs of a chain call -> the handle's buffers, on its own stream (x0 / bs_star / x0s: this handle's chains only)
+int chain_begin(fbsmi_lg_sweep* s, const uint32_t* key, const float* x0, const float* y0, const int32_t* bs_star, float* x0s,
+                hipStream_t ust) {
     const LgDev& d = s->d;
     const size_t C = d.C, T1 = d.T + 1;
     FBSMI_HIP_TRY(hipEventRecord(s->ev_in, ust));
@@ -3176,17 +3179,76 @@ int fbsmi_lg_gibbs_chain(fbsmi_lg_sweep* s, uint32_t* key, float* x0, const floa
     FBSMI_HIP_TRY(hipMemcpyAsync(d.x0s_slot, &x0s, sizeof(float*), hipMemcpyHostToDevice, s->stream));
     // the slot copy reads a host stack variable: make sure it has landed before we return
     FBSMI_HIP_TRY(hipStreamSynchronize(s->stream));
-    for (int i = 0; i < nsweeps; ++i) {
-        int rc = run_sweep(s, 1, use_graph);
-        if (rc) return rc;
-    }
-    FBSMI_HIP_TRY(hipMemcpyAsync(key, d.key, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+    return FBSMI_OK;
+}
+
+int chain_end(fbsmi_lg_sweep* s, uint32_t* key, float* x0, int32_t* bs_star, hipStream_t ust) {
+    const LgDev& d = s->d;
+    const size_t C = d.C, T1 = d.T + 1;
+    if (key) FBSMI_HIP_TRY(hipMemcpyAsync(key, d.key, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
     FBSMI_HIP_TRY(hipMemcpyAsync(x0, d.x0, C * d.du * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     FBSMI_HIP_TRY(hipMemcpyAsync(bs_star, d.bs, C * T1 * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
     int rc = collect_profile(s);
     if (rc) return rc;
     FBSMI_HIP_TRY(hipEventRecord(s->ev_out, s->stream));
     FBSMI_HIP_TRY(hipStreamWaitEvent(ust, s->ev_out, 0));
+    return FBSMI_OK;
+}
+}  // namespace
+
+int fbsmi_lg_gibbs_chain(fbsmi_lg_sweep* s, uint32_t* key, float* x0, const float* y0, int32_t* bs_star,
+                         int32_t nsweeps, float* x0s, int use_graph, void* stream) {
+    if (!s || !key || !x0 || !y0 || !bs_star || nsweeps < 0) return fail(FBSMI_ERR_ARG, "lg_gibbs_chain: bad arguments");
+    hipStream_t ust = (hipStream_t)stream;
+    int rc = chain_begin(s, key, x0, y0, bs_star, x0s, ust);
+    if (rc) return rc;
+    for (int i = 0; i < nsweeps; ++i) {
+        rc = run_sweep(s, 1, use_graph);
+        if (rc) return rc;
+    }
+    return chain_end(s, key, x0, bs_star, ust);
+}
+
+int fbsmi_lg_sweep_set_group(fbsmi_lg_sweep* s, int32_t nchains_total, int32_t first_chain) {
+    if (!s || nchains_total < s->d.C || first_chain < 0 || first_chain + s->d.C > nchains_total)
+        return fail(FBSMI_ERR_ARG, "lg_sweep_set_group: bad arguments");
+    if (s->graph_chain) return fail(FBSMI_ERR_ARG, "lg_sweep_set_group: call it before the handle's first chain sweep");
+    s->d.Ctot = nchains_total;
+    s->d.c0 = first_chain;
+    return FBSMI_OK;
+}
+
+int fbsmi_lg_gibbs_chain_groups(fbsmi_lg_sweep* const* groups, int32_t ngroups, uint32_t* key, float* x0, const float* y0,
+                                int32_t* bs_star, int32_t nsweeps, float* x0s, int use_graph, void* stream) {
+    if (!groups || ngroups < 1 || !key || !x0 || !y0 || !bs_star || nsweeps < 0)
+        return fail(FBSMI_ERR_ARG, "lg_gibbs_chain_groups: bad arguments");
+    hipStream_t ust = (hipStream_t)stream;
+    int expect = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        fbsmi_lg_sweep* s = groups[g];
+        if (!s || s->d.c0 != expect || s->d.Ctot != groups[0]->d.Ctot || s->d.T != groups[0]->d.T || s->d.du != groups[0]->d.du)
+            return fail(FBSMI_ERR_ARG, "lg_gibbs_chain_groups: the handles must cover chains 0 .. Ctot-1 in order (set_group)");
+        expect += s->d.C;
+    }
+    if (expect != groups[0]->d.Ctot) return fail(FBSMI_ERR_ARG, "lg_gibbs_chain_groups: the handles do not cover the batch");
+    for (int g = 0; g < ngroups; ++g) {
+        fbsmi_lg_sweep* s = groups[g];
+        const size_t c0 = s->d.c0;
+        int rc = chain_begin(s, key, x0 + c0 * s->d.du, y0, bs_star + c0 * (s->d.T + 1), x0s, ust);
+        if (rc) return rc;
+    }
+    // sweeps outermost: every group's stream always has work queued, and the groups' launches interleave on the GPU
+    for (int i = 0; i < nsweeps; ++i)
+        for (int g = 0; g < ngroups; ++g) {
+            int rc = run_sweep(groups[g], 1, use_graph);
+            if (rc) return rc;
+        }
+    for (int g = 0; g < ngroups; ++g) {
+        fbsmi_lg_sweep* s = groups[g];
+        const size_t c0 = s->d.c0;
+        int rc = chain_end(s, g == 0 ? key : nullptr, x0 + c0 * s->d.du, bs_star + c0 * (s->d.T + 1), ust);
+        if (rc) return rc;
+    }
     return FBSMI_OK;
 }
 

@@ -20,6 +20,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -238,15 +240,31 @@ class LGSweep:
     gibbs_kernel); with nchains > 1 every per-chain array carries a leading axis of that size, like
     the reference's jax.vmap(gibbs_kernel, in_axes=[0, 0, None, 0, 0]) (gp_gibbs.py:173)."""
 
-    def __init__(self, model: LinearGaussianBridge, nparticles, eb, ef, store, nchains=1):
+    def __init__(self, model: LinearGaussianBridge, nparticles, eb, ef, store, nchains=1, _group=None):
         self.model = model
         self.nparticles, self.eb, self.ef, self.store, self.C = nparticles, eb, ef, store, int(nchains)
+        self.n_rows = nparticles + 1 if ef else nparticles
+        self.children, self.h = [], None
+        # A batch of four or more chains is driven as two handles of half the chains each, on their own streams: the step
+        # kernels are latency-bound, so the two halves' launches interleave and finish sooner than one full-size batch
+        # (same results bit for bit; FBSMI_CHAIN_GROUPS=1 keeps one handle, =k asks for k groups).
+        G = 1
+        if _group is None:
+            G = int(os.environ.get("FBSMI_CHAIN_GROUPS", "0")) or (2 if self.C >= 4 else 1)
+            if G < 1 or self.C % G:
+                G = 1
+        if G > 1:
+            per = self.C // G
+            self.children = [LGSweep(model, nparticles, eb, ef, store, per, _group=(self.C, g * per)) for g in range(G)]
+            self._harr = (C.c_void_p * G)(*[c.h for c in self.children])
+            return
         h = C.c_void_p()
         with torch.cuda.device(model.device):
             _lib.call("fbsmi_lg_sweep_create", C.byref(model.struct), nparticles, int(eb), int(ef), int(store),
                       self.C, C.byref(h))
         self.h = h
-        self.n_rows = nparticles + 1 if ef else nparticles
+        if _group is not None:
+            _lib.call("fbsmi_lg_sweep_set_group", self.h, int(_group[0]), int(_group[1]))
 
     def __del__(self):
         try:
@@ -271,6 +289,16 @@ class LGSweep:
     def sweep(self, key, x0, y0, bs_star, use_graph=True):
         """key (C,2) [or (2,)], x0 (C,du), y0 (dv,), bs_star (C,T+1) -> (x0, us_star, bs_star, acc)."""
         m, Cn = self.model, self.C
+        if self.children:     # every group sweeps its chains (explicit per-chain keys: nothing to coordinate)
+            k2 = np.asarray(key.detach().cpu() if isinstance(key, torch.Tensor) else key).reshape(Cn, 2)
+            x2 = self._dev(x0, torch.float32, (Cn, m.du))
+            b2 = self._dev(bs_star, torch.int32, (Cn, m.T + 1))
+            outs, c0 = [], 0
+            for ch in self.children:
+                o = ch.sweep(k2[c0:c0 + ch.C], x2[c0:c0 + ch.C], y0, b2[c0:c0 + ch.C], use_graph=use_graph)
+                outs.append([t.reshape((ch.C,) + tuple(t.shape[(0 if ch.C == 1 else 1):])) for t in o])
+                c0 += ch.C
+            return tuple(torch.cat([o[i] for o in outs], dim=0) for i in range(4))
         kt = self._key_t(key, Cn)
         x0t = self._dev(x0, torch.float32, (Cn, m.du))
         y0t = self._dev(y0, torch.float32, (m.dv,))
@@ -293,8 +321,12 @@ class LGSweep:
         y0t = self._dev(y0, torch.float32, (m.dv,))
         bst = self._dev(bs_star, torch.int32, (Cn, m.T + 1)).clone()
         x0s = torch.empty((nsweeps, Cn, m.du), dtype=torch.float32, device=m.device) if keep else None
-        _lib.call("fbsmi_lg_gibbs_chain", self.h, kt.data_ptr(), x0t.data_ptr(), y0t.data_ptr(), bst.data_ptr(),
-                  int(nsweeps), x0s.data_ptr() if keep else None, int(bool(use_graph)), ops._stream())
+        if self.children:
+            _lib.call("fbsmi_lg_gibbs_chain_groups", self._harr, len(self.children), kt.data_ptr(), x0t.data_ptr(), y0t.data_ptr(),
+                      bst.data_ptr(), int(nsweeps), x0s.data_ptr() if keep else None, int(bool(use_graph)), ops._stream())
+        else:
+            _lib.call("fbsmi_lg_gibbs_chain", self.h, kt.data_ptr(), x0t.data_ptr(), y0t.data_ptr(), bst.data_ptr(),
+                      int(nsweeps), x0s.data_ptr() if keep else None, int(bool(use_graph)), ops._stream())
         key_out = kt.cpu().numpy().view(np.uint32).reshape(2).copy()
         if keep and Cn == 1:
             x0s = x0s[:, 0]
@@ -304,6 +336,11 @@ class LGSweep:
         """Parity views of the last sweep's CSMC forward pass (copies; leading chain axis if C > 1)."""
         m = self.model
         N, Cn = self.n_rows, self.C
+        if self.children:
+            parts = [ch.views() for ch in self.children]
+            cat = lambda name: None if parts[0][name] is None else torch.cat(
+                [p[name].reshape((ch.C,) + tuple(p[name].shape[(0 if ch.C == 1 else 1):])) for p, ch in zip(parts, self.children)], dim=0)
+            return {name: cat(name) for name in parts[0]}
         spec = {"us_T": (0, torch.float32, (N, m.du)), "lw_T": (1, torch.float32, (N,)),
                 "As": (2, torch.int32, (m.T, N)), "uss": (3, torch.float32, (m.T + 1, N, m.du)),
                 "log_wss": (4, torch.float32, (m.T + 1, N)), "us_star": (5, torch.float32, (m.T + 1, m.du)),
@@ -321,9 +358,13 @@ class LGSweep:
         return out
 
     def profile(self, enable: bool):
+        if self.children:
+            raise RuntimeError("profile one group of a grouped batch: sweep.children[0].profile(...)")
         _lib.call("fbsmi_lg_sweep_profile", self.h, int(bool(enable)))
 
     def kernel_us(self, which: int):
+        if self.children:
+            return self.children[0].kernel_us(which)
         avg = C.c_double()
         n = C.c_int64()
         _lib.call("fbsmi_lg_sweep_kernel_us", self.h, int(which), C.byref(avg), C.byref(n))

@@ -173,6 +173,15 @@ int fbsmi_lg_gibbs_sweep(fbsmi_lg_sweep* s, const uint32_t* keys, const float* x
  * bs_star (C,T+1) are updated in place; x0s (nullable) receives (nsweeps, C, du). */
 int fbsmi_lg_gibbs_chain(fbsmi_lg_sweep* s, uint32_t* key, float* x0, const float* y0, int32_t* bs_star,
                          int32_t nsweeps, float* x0s, int use_graph, void* stream);
+/* A batch of chains may be driven as several handles ("groups") of fewer chains each, on their own streams: the step
+ * kernels of a toy-sized ensemble are latency-bound (~3 us of every launch are its boundaries), so two half-size batches
+ * whose launches interleave finish sooner than one full-size batch.  set_group tells a handle which chains of the batch it
+ * drives (key schedule split(subkey, nchains_total)[first_chain + c], rows of x0s); call it before the handle's first
+ * chain sweep.  chain_groups is fbsmi_lg_gibbs_chain over the handles (which must cover chains 0 .. nchains_total-1 in
+ * order): same arguments, same results bit for bit, per-chain arrays laid out for the whole batch. */
+int fbsmi_lg_sweep_set_group(fbsmi_lg_sweep* s, int32_t nchains_total, int32_t first_chain);
+int fbsmi_lg_gibbs_chain_groups(fbsmi_lg_sweep* const* groups, int32_t ngroups, uint32_t* key, float* x0, const float* y0,
+                                int32_t* bs_star, int32_t nsweeps, float* x0s, int use_graph, void* stream);
 /* Parity views of the last sweep: copies view `which` into dst (device, nullable) and reports its
  * element count.  which: 0 final particles (n,du) row-major, 1 final normalised log-weights (n),
  * 2 As (T,n) int32, 3 uss (T+1,n,du), 4 log_wss (T+1,n) [2-4 only with store_path],

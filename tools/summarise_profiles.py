@@ -126,6 +126,7 @@ def main():
                    "--steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan '' --image-steps 0 --sharded-steps 0",
         "workload_text": cfg.get("workload"),
         "workload": {"nparticles": cfg.get("nparticles"), "nsteps": cfg.get("nsteps"), "nchains": cfg.get("nchains")},
+        "chains_per_launch": bench["roofline"].get("chains_per_launch", cfg.get("nchains")),
         "kernel": k.replace("void fbsmi::", ""),
         "fetch_correction_4_bytes_per_lane": f4,
         "bytes_per_launch": ((fkb * (f4 or 1.0)) + wkb) * 1024.0,
