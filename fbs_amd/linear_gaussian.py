@@ -250,7 +250,10 @@ class LGSweep:
         # (same results bit for bit; FBSMI_CHAIN_GROUPS=1 keeps one handle, =k asks for k groups).
         G = 1
         if _group is None:
-            G = int(os.environ.get("FBSMI_CHAIN_GROUPS", "0")) or (2 if self.C >= 4 else 1)
+            # (wide models: four groups -- their sweeps are long enough for the host to feed four graphs; narrow ones: two,
+            # four were measured host-bound, 13.7 against 8.0 ms per sweep)
+            wide = max(model.du, model.dv) > 16
+            G = int(os.environ.get("FBSMI_CHAIN_GROUPS", "0")) or ((4 if (wide and self.C % 4 == 0) else 2) if self.C >= 4 else 1)
             if G < 1 or self.C % G:
                 G = 1
         if G > 1:
