@@ -1827,7 +1827,9 @@ __device__ __forceinline__ void lgw_fpre_body(const LgDev& d, int kres, bool sto
 // The drift product and what hangs on it.  nrt = row tiles = ceil(D / 32); Kp = D rounded up to a multiple of
 // 16, Q = Kp / 4.  LDS tiles are [32][S] with column c stored at (c % 4) * Q + c / 4: lane group g of an
 // MFMA (which supplies column 4q + g of instruction q) then finds its columns of four consecutive
-// instructions in one aligned float4.  S % 64 == 4: the 16 lanes of a ds_read_b128 pass cover all 64 banks.
+// instructions in one aligned float4.  S = Kp + 4, i.e. S / 4 odd: the 16 lanes of a ds_read_b128 pass (16 consecutive rows,
+// one aligned float4 each) start at 16 different bank quads and cover all 64 banks.  (S used to be padded up to 4 mod 64 --
+// 260 floats for D = 200 --; at 212 a large-ensemble workgroup needs 54 KB instead of 66 and three fit a CU.)
 // KIND: where the ancestors come from -- 0: d.anc (k_lgw_anc); 1: the Gibbs step prologue, in this
 // workgroup; 2: the filter prologue (resampling key of step kres), in this workgroup; 3: identity (no
 // resampling in front of this product); 4: d.anc again, with the filters' conventions (k_lgwf_anc).  tr0 / nrt: the row tiles of this launch; emit bit 0: rows < du
@@ -2801,7 +2803,7 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     k_lg_path<<<dim3(gpath, d.C), 64, 0, st>>>(d, 0);
     // wide models: MFMA drift, one workgroup per (32 slots, 32 drift rows)
     const int w_nrt = (d.D + kWideTile - 1) / kWideTile, w_Kp = (d.D + 15) / 16 * 16;
-    const int w_S = w_Kp + ((68 - w_Kp % 64) % 64);   // >= Kp, == 4 (mod 64)
+    const int w_S = w_Kp + 4;   // S / 4 odd (Kp is a multiple of 16)
     const size_t w_lds = sizeof(float) * 2 * kWideTile * (size_t)w_S;
     const dim3 gwide(((d.N + kWideTile - 1) / kWideTile) * w_nrt, d.C);
     if (d.wide) {
@@ -3104,7 +3106,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     if (wide) {
         // The attribute belongs to the function, not to the handle: always ask for the largest tile pair any model can
         // need (D = 256), or a later handle with a smaller model would lower the limit under an earlier one.
-        constexpr int kKpMax = 256, kSMax = kKpMax + ((68 - kKpMax % 64) % 64);
+        constexpr int kKpMax = 256, kSMax = kKpMax + 4;
         const int lds = (int)(sizeof(float) * 2 * kWideTile * kSMax);
         hipError_t e = hipFuncSetAttribute((const void*)k_lgw_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -3301,7 +3303,7 @@ int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
     }
     if (d.wide) {
         // N <= 256: a launch = [filter prologue +] drift product
-        const int nrt = (d.D + kWideTile - 1) / kWideTile, Kp = (d.D + 15) / 16 * 16, S = Kp + ((68 - Kp % 64) % 64);
+        const int nrt = (d.D + kWideTile - 1) / kWideTile, Kp = (d.D + 15) / 16 * 16, S = Kp + 4;
         const size_t lds = sizeof(float) * 2 * kWideTile * (size_t)S;
         const int nst = (d.N + kWideTile - 1) / kWideTile;
         const int u_tiles = (d.du + kWideTile - 1) / kWideTile;   // row tiles holding rows < du
