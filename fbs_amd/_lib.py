@@ -109,6 +109,7 @@ SIGNATURES = {
     "fbsmi_nn_linear_attention": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp]),
     "fbsmi_nn_qkv_linear_attention": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "fbsmi_nn_conv3x3": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "fbsmi_nn_proj64": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _f, _vp, _vp, _i64, _vp]),
     "fbsmi_nn_channel_layernorm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _vp, _f, _vp, _vp, _vp]),
     "fbsmi_nn_groupnorm_silu": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fbsmi_nn_bias_add": (C.c_int, [_vp, C.c_int, _i64, _i32, _vp, _vp]),

@@ -468,6 +468,124 @@ __global__ void __launch_bounds__(64 * NW) k_conv3x3(const __hip_bfloat16* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// 1x1 projection to 64 channels on the matrix cores, with what follows it in the network folded in:
+//   y = [LN_c]( a Wa^T [+ b Wb^T] [+ bias] ) [* scale] [+ residual]
+// a, b: token-major bfloat16 inputs of CKA * 16 / CKB * 16 channels whose concatenation the weight (64, Ka + Kb) multiplies
+// (the up path's (h, skip) pairs: the concatenation is never formed); LN_c: the channel LayerNorm of LinearAttention's to_out
+// (no bias, eps), `residual` the attention block's skip connection.  A wave takes 32 pixels: the product is formed
+// transposed (channels in the registers, the pixel on the lane) from operand fragments read straight from memory (every
+// activation element is read once: nothing to stage), the 64 channels of a pixel are then two accumulator tiles of ITS lane
+// pair, so the LayerNorm statistics are in-lane sums plus one exchange; rows leave through an LDS park as in k_conv3x3.
+// ------------------------------------------------------------------------------------------
+template <int CKA, int CKB, bool LN>
+__global__ void __launch_bounds__(256) k_proj64(const __hip_bfloat16* __restrict__ a, const __hip_bfloat16* __restrict__ b,
+                                                const __hip_bfloat16* __restrict__ w, const float* __restrict__ bias,
+                                                const float* __restrict__ scale, float eps,
+                                                const __hip_bfloat16* __restrict__ residual, __hip_bfloat16* __restrict__ y,
+                                                long long npix) {
+    constexpr int CK = CKA + CKB, K = 16 * CK, kRow = 128 + 16;
+    __shared__ __attribute__((aligned(16))) char park_all[4 * 32 * kRow];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
+    bf16x8 wf[2][CK];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int s = 0; s < CK; ++s)
+            wf[nb][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + (size_t)(32 * nb + r) * K + 16 * s + 8 * h2));
+    float bs[2][4][4];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bs[nb][c][i] = bias ? bias[32 * nb + 8 * c + 4 * h2 + i] : 0.0f;
+    char* park = park_all + wave * 32 * kRow;
+    const long long ntile = (npix + 31) / 32;
+    for (long long t = (long long)blockIdx.x * 4 + wave; t < ntile; t += (long long)gridDim.x * 4) {
+        const long long p = t * 32 + r;
+        const bool pv = p < npix;
+        const long long pp = pv ? p : npix - 1;
+        f32x16 acc[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
+        const uint4* pa = reinterpret_cast<const uint4*>(a + pp * (16 * CKA) + 8 * h2);
+        uint4 xa[CK];
+#pragma unroll
+        for (int s = 0; s < CKA; ++s) xa[s] = pa[2 * s];
+        if (CKB > 0) {
+            const uint4* pb = reinterpret_cast<const uint4*>(b + pp * (16 * CKB) + 8 * h2);
+#pragma unroll
+            for (int s = 0; s < CKB; ++s) xa[CKA + s] = pb[2 * s];
+        }
+#pragma unroll
+        for (int s = 0; s < CK; ++s) {
+            const bf16x8 xf = __builtin_bit_cast(bf16x8, xa[s]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][s], xf, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][s], xf, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nb][i] += bs[nb][i >> 2][i & 3];
+        if (LN) {   // this pixel's 64 channels: 2 x 16 registers here, the other 32 on lane ^ 32
+            float sm = 0.0f;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sm += acc[nb][i];
+            sm += __shfl_xor(sm, 32);
+            const float mean = sm * (1.0f / 64.0f);
+            float q = 0.0f;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) q += (acc[nb][i] - mean) * (acc[nb][i] - mean);
+            q += __shfl_xor(q, 32);
+            const float rs = rsqrtf(q * (1.0f / 64.0f) + eps);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    acc[nb][i] = (acc[nb][i] - mean) * rs * scale[32 * nb + 8 * (i >> 2) + 4 * h2 + (i & 3)];
+        }
+        // rows out (see k_conv3x3): 4-channel groups -> 16-byte chunks by swapping between the lane halves, parked, read back
+        // along the rows; the residual joins there, with whole-row loads
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16& A = acc[nb];
+                const unsigned p0x = pk_bf16(A[8 * j], A[8 * j + 1]), p0y = pk_bf16(A[8 * j + 2], A[8 * j + 3]);
+                const unsigned p1x = pk_bf16(A[8 * j + 4], A[8 * j + 5]), p1y = pk_bf16(A[8 * j + 6], A[8 * j + 7]);
+                const auto rx = __builtin_amdgcn_permlane32_swap(p0x, p1x, false, false);
+                const auto ry = __builtin_amdgcn_permlane32_swap(p0y, p1y, false, false);
+                *reinterpret_cast<uint4*>(park + r * kRow + nb * 64 + (2 * j + h2) * 16) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            }
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+            const int row = lane / 8 + rd * 8, ch = lane % 8;
+            uint4 u = *reinterpret_cast<const uint4*>(park + row * kRow + ch * 16);
+            const long long pr = t * 32 + row;
+            if (pr < npix) {
+                if (residual) {
+                    const uint4 o = *reinterpret_cast<const uint4*>(residual + pr * 64 + 8 * ch);
+                    const unsigned ow[4] = {o.x, o.y, o.z, o.w}, uw[4] = {u.x, u.y, u.z, u.w};
+                    unsigned rw[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        rw[k] = pk_bf16(__uint_as_float(ow[k] << 16) + __uint_as_float(uw[k] << 16),
+                                        __uint_as_float(ow[k] & 0xffff0000u) + __uint_as_float(uw[k] & 0xffff0000u));
+                    u = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+                }
+                *reinterpret_cast<uint4*>(y + pr * 64 + 8 * ch) = u;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // GroupNorm + modulation + SiLU.  One workgroup per image; a thread owns one aligned 8-channel vector slot
 // (always inside one group, since the group size is a multiple of 8) across a strided set of tokens:
 // pass 1 Welford-merges its vectors into (count, mean, M2), the slots of a group are merged through LDS
@@ -873,6 +991,32 @@ extern "C" int fbsmi_nn_conv3x3(const void* x, int32_t xstride, const void* w, i
 #undef FBSMI_CONV_LAUNCH
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
     e = hipGetLastError();
+    if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
+    return FBSMI_OK;
+}
+
+extern "C" int fbsmi_nn_proj64(const void* a, int32_t Ca, const void* b, int32_t Cb, const void* w, const float* bias,
+                               const float* ln_scale, float eps, const void* residual, void* y, int64_t npix, void* stream) {
+    if (!a || !w || !y || npix < 0 || (Cb > 0 && !b)) return fail(FBSMI_ERR_ARG, "nn_proj64: bad arguments");
+    if (!((Ca == 64 || Ca == 128) && (Cb == 0 || Cb == 64)) || (Ca == 128 && Cb != 0))
+        return fail(FBSMI_ERR_UNSUPPORTED, "nn_proj64: inputs of (64), (128) or (64, 64) channels");
+    if (npix == 0) return FBSMI_OK;
+    const long long tiles = (npix + 31) / 32, wgs = (tiles + 3) / 4;
+    const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);
+    hipStream_t st = (hipStream_t)stream;
+    const __hip_bfloat16 *a_ = (const __hip_bfloat16*)a, *b_ = (const __hip_bfloat16*)b, *w_ = (const __hip_bfloat16*)w,
+                         *r_ = (const __hip_bfloat16*)residual;
+    __hip_bfloat16* y_ = (__hip_bfloat16*)y;
+#define FBSMI_PROJ(CKA_, CKB_)                                                                                   \
+    {                                                                                                            \
+        if (ln_scale) k_proj64<CKA_, CKB_, true><<<grid, 256, 0, st>>>(a_, b_, w_, bias, ln_scale, eps, r_, y_, npix);  \
+        else k_proj64<CKA_, CKB_, false><<<grid, 256, 0, st>>>(a_, b_, w_, bias, ln_scale, eps, r_, y_, npix);          \
+    }
+    if (Ca == 128) FBSMI_PROJ(8, 0)
+    else if (Cb == 64) FBSMI_PROJ(4, 4)
+    else FBSMI_PROJ(4, 0)
+#undef FBSMI_PROJ
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FBSMI_ERR_HIP, hipGetErrorString(e));
     return FBSMI_OK;
 }

@@ -201,6 +201,31 @@ def _w16_of(conv: nn.Conv2d):
     return conv._w16
 
 
+def _proj64_fusable(parts, cout) -> bool:
+    chans = tuple(t.shape[1] for t in parts)
+    return (cout == 64 and chans in ((64,), (128,), (64, 64)) and not torch.is_grad_enabled()
+            and all(t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous(memory_format=torch.channels_last) for t in parts))
+
+
+def _proj64(parts, conv: nn.Conv2d, with_bias=True, ln=None, residual=None):
+    """fbsmi_nn_proj64: the 1x1 convolution `conv` (to 64 channels) of the concatenation of `parts`, optionally followed by
+    the channel LayerNorm `ln` and a residual, in one kernel.  -> NCHW view of a (B, H, W, 64) tensor."""
+    from . import _lib
+    a = parts[0]
+    b = parts[1] if len(parts) > 1 else None
+    B, _, H, W = a.shape
+    out = torch.empty((B, H, W, 64), dtype=torch.bfloat16, device=a.device)
+    res = None
+    if residual is not None:
+        res = residual if (residual.dtype == torch.bfloat16 and residual.is_contiguous(memory_format=torch.channels_last)) \
+            else residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    _lib.call("fbsmi_nn_proj64", a.data_ptr(), a.shape[1], b.data_ptr() if b is not None else None, b.shape[1] if b is not None else 0,
+              _w16_of(conv).data_ptr(), conv.bias.data_ptr() if (with_bias and conv.bias is not None) else None,
+              ln.scale.data_ptr() if ln is not None else None, float(ln.eps) if ln is not None else 0.0,
+              res.data_ptr() if res is not None else None, out.data_ptr(), B * H * W, torch.cuda.current_stream().cuda_stream)
+    return out.permute(0, 3, 1, 2)
+
+
 def _conv1x1(x, weight):
     """A 1x1 convolution without bias.  On channels_last inference activations it is a plain GEMM over the token-major view
     (rows = pixels), which the BLAS library runs near the memory rate; MIOpen's implicit-GEMM kernel takes 2-3x as long for
@@ -282,7 +307,9 @@ class ResnetBlock(nn.Module):
             # the convolution biases are added inside the normalisation kernel (one pass less over the activations)
             h = _gn_silu(self.conv_0(x, with_bias=False), self.norm_0, scale, shift, self.conv_0.conv.bias)
             rbias = None
-            if self.res_conv is not None:     # its bias rides on the same kernel as the skip connection it feeds
+            if self.res_conv is not None and _proj64_fusable(_as_parts(x), self.res_conv.out_channels):
+                x = _proj64(_as_parts(x), self.res_conv)          # both parts and the bias in one kernel
+            elif self.res_conv is not None:   # its bias rides on the same kernel as the skip connection it feeds
                 x, rbias = _conv1x1(x, self.res_conv.weight), self.res_conv.bias
             # ... and so is the skip connection: x + silu(norm_1(conv_1(h)))
             return _gn_silu(self.conv_1(h, with_bias=False), self.norm_1, None, None, self.conv_1.conv.bias, residual=x,
@@ -338,6 +365,8 @@ class LinearAttention(nn.Module):
         B, C, H, W = x.shape
         if x.is_cuda and self.dim_head == 32 and not torch.is_grad_enabled():
             core = self._fused_qkv_core(x, B, H, W) if self._qkv_fusable(x) else self._fused_core(self.to_qkv(x), B, H, W)
+            if _proj64_fusable((core,), self.to_out.out_channels) and (residual is None or residual.shape[1] == 64):
+                return _proj64((core,), self.to_out, ln=self.to_out_norm, residual=residual)   # to_out + norm + skip connection
             y = _conv1x1(core, self.to_out.weight)
             return self.to_out_norm(y, residual, xbias=self.to_out.bias)
         if residual is not None:

@@ -37,6 +37,15 @@ int fbsmi_nn_qkv_linear_attention(const void* xn, const void* w, void* out, int6
 int fbsmi_nn_conv3x3(const void* x, int32_t xstride, const void* w, int32_t wstride, int32_t ci_off, const float* bias, void* y,
                      int accumulate, int64_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
 
+/* 1x1 projection to 64 channels, bfloat16 on the matrix cores, with its consumer folded in:
+ *   y = [LN_c]( a Wa^T [+ b Wb^T] [+ bias] ) [* ln_scale] [+ residual]
+ * a (npix, Ca), b (npix, Cb) or NULL: token-major inputs whose concatenation w (64, Ca + Cb) multiplies ((Ca, Cb) in
+ * {(64, 0), (128, 0), (64, 64)}); bias (64) float32 or NULL; ln_scale (64) float32 or NULL: when given, the channel
+ * LayerNorm (no bias, eps) of LinearAttention's to_out (fbs/nn/unet.py:228-232) is applied to the biased product;
+ * residual (npix, 64) or NULL is added last; y (npix, 64). */
+int fbsmi_nn_proj64(const void* a, int32_t Ca, const void* b, int32_t Cb, const void* w, const float* bias,
+                    const float* ln_scale, float eps, const void* residual, void* y, int64_t npix, void* stream);
+
 /* GroupNorm (biased variance, eps) + per-image channel modulation + SiLU in one pass over the activations --
  * the two normalisation sites of ResnetBlock (fbs/nn/unet.py:127-172):
  *   x' = x + xbias[c]   (the bias of the convolution that produced x, folded in here; NULL: none)

@@ -249,6 +249,32 @@ def test_conv3x3_over_channel_slices_and_unconcatenated_inputs(B, H, W, parts, c
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,chans,ln", [(3, 28, 28, (128,), True), (2, 9, 7, (64, 64), False), (5, 5, 5, (64,), False),
+                                           (1, 64, 64, (128,), True), (2, 14, 14, (64, 64), True)])
+def test_proj64_with_layernorm_and_residual(B, H, W, chans, ln):
+    """fbsmi_nn_proj64 (1x1 projection of one or two inputs to 64 channels [+ channel LayerNorm] [+ residual]) against the
+    float32 torch ops on the same bfloat16-rounded operands."""
+    from fbs_amd.unet import _ChannelLayerNorm, _proj64, _proj64_fusable
+    dev = torch.device("cuda:0")
+    torch.manual_seed(sum(chans) + B)
+    parts = tuple(torch.randn(B, c, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for c in chans)
+    conv = torch.nn.Conv2d(sum(chans), 64, 1).to(dev)
+    norm = _ChannelLayerNorm(64).to(dev)
+    res = torch.randn(B, 64, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        norm.scale.uniform_(0.5, 1.5)
+        assert _proj64_fusable(parts, 64)
+        got = _proj64(parts, conv, ln=norm if ln else None, residual=res).float()
+        w16 = conv.weight.to(torch.bfloat16).float()
+        y = torch.nn.functional.conv2d(torch.cat([t.float() for t in parts], dim=1), w16, conv.bias)
+        if ln:
+            y = (y - y.mean(1, keepdim=True)) * torch.rsqrt(y.var(1, unbiased=False, keepdim=True) + 1e-5) * norm.scale.view(1, -1, 1, 1)
+        want = y + res.float()
+    assert got.shape == want.shape
+    assert bool(((got - want).abs() <= 2.0 ** -7 * want.abs() + 2e-2).all()), (got - want).abs().max().item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_bias_folds_and_pixel_shuffle_kernels(dtype):
     """fbsmi_nn_bias_add / fbsmi_nn_pixel_shuffle (+ bias) / the xbias of the channel LayerNorm against the torch ops they replace:
