@@ -23,12 +23,18 @@ and eps 1e-5, ``jax.image.resize(..., 'linear')`` = bilinear with half-pixel cen
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+# FBSMI_NN_MFMA=0 keeps the convolutions / projections / qkv-attention on the library paths (MIOpen, hipBLASLt, the round-1
+# attention kernel): an A/B switch for timing and for chasing numerical differences; the glue kernels stay on.
+_MFMA_KERNELS = os.environ.get("FBSMI_NN_MFMA", "1") != "0"
 
 
 def sinusoidal_embedding(t: torch.Tensor, out_dim: int = 64, max_period: int = 10_000) -> torch.Tensor:
@@ -157,6 +163,8 @@ def _conv3x3_fusable(x, weight, stride=(1, 1), padding=(1, 1)) -> bool:
     128 -- one tensor or several (their concatenation is then never formed)."""
     parts = _as_parts(x)
     x0 = parts[0]
+    if not _MFMA_KERNELS:
+        return False
     if not (x0.is_cuda and not torch.is_grad_enabled() and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1)
             and tuple(padding) == (1, 1) and weight.shape[0] % 64 == 0 and sum(t.shape[1] for t in parts) == weight.shape[1]):
         return False
@@ -203,7 +211,7 @@ def _w16_of(conv: nn.Conv2d):
 
 def _proj64_fusable(parts, cout) -> bool:
     chans = tuple(t.shape[1] for t in parts)
-    return (cout == 64 and chans in ((64,), (128,), (64, 64)) and not torch.is_grad_enabled()
+    return (_MFMA_KERNELS and cout == 64 and chans in ((64,), (128,), (64, 64)) and not torch.is_grad_enabled()
             and all(t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous(memory_format=torch.channels_last) for t in parts))
 
 
@@ -400,7 +408,7 @@ def _linear_attention_core(self, qkv, B, H, W):
 
 def _qkv_fusable(self, x) -> bool:
     """bfloat16 activations (the autocast network), C in {16, 32, 64, 128}: to_qkv runs inside the attention kernel."""
-    return (x.dtype == torch.bfloat16 and x.shape[1] in (16, 32, 64, 128)
+    return (_MFMA_KERNELS and x.dtype == torch.bfloat16 and x.shape[1] in (16, 32, 64, 128)
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
