@@ -2467,7 +2467,7 @@ __global__ void __launch_bounds__(kBlock) k_filt_init(LgDev dd, const float* u0s
 }
 
 // fnorm: c = logsumexp(lw); accumulate the (negative) log-likelihood; w = exp(lw - c); partials
-template <int ITEMS>
+template <int ITEMS, bool PUB = false>   // PUB: publish the tile's part of the summation tree (two-launch filter step)
 __global__ void __launch_bounds__(kBlock) k_filt_norm(LgDev dd) {
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float xch[3][4];
@@ -2491,6 +2491,16 @@ __global__ void __launch_bounds__(kBlock) k_filt_norm(LgDev dd) {
     float s1[1] = {chunk_total<ITEMS>(xw)}, t1[1];
     TreePath p1[1];
     block_upsweep_n<1>(s1, p1, xch[2], t1);
+    if (PUB && ITEMS == 1) {   // as k_lg_norm<1, 0, true>: the midpoints of the nodes of 8 leaves and more
+        const int i = threadIdx.x;
+        if ((i & 3) == 0) {
+            const int h = i ? tree_mid_node(i) : 0;
+            const float2 node = make_float2(i ? tree_left_sum(p1[0], i) : 0.0f, xw[0]);
+            d.trW[(size_t)blockIdx.x * kTreeNodes + h] = node;
+            if (h < kMidN) d.trWtop[blockIdx.x * kMidN + h] = node;
+            if (i == 0) d.wfirst[blockIdx.x] = node.y;
+        }
+    }
     if (threadIdx.x == 0) {
         d.bsumw[blockIdx.x] = t1[0];
         if (blockIdx.x == 0) {
@@ -2585,6 +2595,106 @@ __global__ void __launch_bounds__(kBlock) k_filt_prop(LgDev dd, int s, int resam
     if (weight) {
         float mx, sx;
         block_lse_partial<ITEMS>(lv, xch[0], xch[1], mx, sx);
+        if (threadIdx.x == 0) {
+            d.bmax[blockIdx.x] = mx;
+            d.bsumexp[blockIdx.x] = sx;
+        }
+    }
+}
+
+// fprop of the TWO-launch filter step (N a power of two, 2..256 tiles; k_filt_norm<1, true> in front, no cdf launch): the
+// stratified / systematic searches walk the summation tree, exactly as the Cat(w) redraws of k_lg_prop1t do -- the top
+// levels rebuilt from the tile sums, three levels of every tile staged in LDS, then the tile's published heap and the last
+// four leaves of w in two round trips.  Same flags and arithmetic as k_filt_prop<1, DMAX>.
+template <int DMAX>
+__global__ void __launch_bounds__(kBlock) k_filt_prop1t(LgDev dd, int s, int resample, int kres, int weight, int propagate) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    __shared__ float xch[3][4];
+    __shared__ __attribute__((aligned(16))) float2 topW[kBlock];
+    __shared__ __attribute__((aligned(16))) float2 midW[kMidN * kBlock];
+    const int N = d.N, nb = d.nb, tid = threadIdx.x;
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    float last = 0.0f;
+    if (resample) {   // (kernel-uniform)
+        const bool tl = tid < nb;
+        const float sw = tl ? d.bsumw[tid] : 0.0f, wf = tl ? d.wfirst[tid] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < kMidN / 2; ++k) {
+            const int idx = tid + kBlock * k;
+            if (idx < kMidN / 2 * nb) reinterpret_cast<float4*>(midW)[idx] = reinterpret_cast<const float4*>(d.trWtop)[idx];
+        }
+        float s1[1] = {sw}, t1[1];
+        TreePath p1[1];
+        block_upsweep_n<1>(s1, p1, xch[2], t1);
+        last = t1[0];                                  // == cdf[N - 1]
+        if (tid) topW[tree_mid_node(tid)] = make_float2(tree_left_sum(p1[0], tid), wf);
+        __syncthreads();
+    }
+    const uint32_t* ktp = d.keytab + 8 * (s < d.T ? s : d.T - 1);
+    const uint32_t p0 = ktp[0], p1k = ktp[1];
+    const uint32_t r0 = d.keytab[8 * kres + 2], r1 = d.keytab[8 * kres + 3];
+    const float u_sys = (resample && d.systematic) ? uniform_at(r0, r1, 1, 0) : 0.0f;
+    const int st = s < d.T ? s : d.T - 1;
+    const StepTables<DMAX> t = step_tables<DMAX>(d, st);
+    const StepTables<DMAX> tn = step_tables<DMAX>(d, st + 1 < d.T ? st + 1 : st);
+    const int m = blockIdx.x * kBlock + tid;   // N is a multiple of the tile: every slot is live
+    float lv[1] = {-__builtin_inff()};
+    int a = m;
+    if (resample) {   // _systematic_or_stratified, resampling.py:43-51
+        const float uu = d.systematic ? u_sys : uniform_at(r0, r1, (uint64_t)N, (uint64_t)m);
+        const float q = ((float)m + uu) / (float)N;
+        float P = 0.0f, E = last;
+        int h = tree_walk_n(topW, kBlock / nb, 31 - __builtin_clz(nb), q, P, E);
+        const int tile = h - kBlock;
+        h = tree_walk_n(midW + tile * kMidN, 1, kMidLv, q, P, E);
+        const TreeRound rd = tree_round_load(d, tile, h);
+        const int lo = tree_round_walk(rd, tile, h, q, P, E);
+        const float4 w4 = *reinterpret_cast<const float4*>(d.w + lo);
+        a = tree_leaves_walk(w4, lo, q, P, E);
+        a = a < 0 ? 0 : (a > N - 1 ? N - 1 : a);
+    }
+    float u[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) u[r] = r < d.du ? up[(size_t)r * N + a] : 0.0f;
+    if (!propagate) {   // final resampling of bootstrap_filter: us[inds]  (smc.py:72)
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r)
+            if (r < d.du) {
+                d.usT[(size_t)m * d.du + r] = u[r];
+                if (d.uss) d.uss[((size_t)d.T * N + m) * d.du + r] = u[r];
+            }
+        return;   // (kernel-uniform; weight == 0 here)
+    }
+    if (d.uss && d.flow == 0 && s > 0) {   // filtering_samples[s] = resampled particles of step s-1
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r)
+            if (r < d.du) d.uss[((size_t)s * N + m) * d.du + r] = u[r];
+    }
+    float x[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) {
+        x[r] = 0.0f;
+        if (r < d.du) {
+            const float dr = drift_row<DMAX>(t, r, u, d.vs + (size_t)s * d.dv);
+            const float z = normal_at(p0, p1k, (uint64_t)N * d.du, (uint64_t)m * d.du + r);
+            x[r] = (u[r] + dr * t.dt) + t.sd * z;                 // transition_sampler
+            un[(size_t)r * N + m] = x[r];
+            if (s == d.T - 1 && d.flow == 1) d.usT[(size_t)m * d.du + r] = x[r];
+        }
+    }
+    if (weight == 1) {         // measurement_cond_pdf(v, us_prev, v_prev, t_prev)      smc.py:65
+        const float l = lg_loglik<DMAX>(t, u, d.vs + (size_t)(s + 1) * d.dv, d.vs + (size_t)s * d.dv);
+        d.lw[m] = l;
+        lv[0] = l;
+    } else if (weight == 2) {  // next step's likelihood_logpdf on the propagated particle  smc.py:144
+        const float l = lg_loglik<DMAX>(tn, x, d.vs + (size_t)(s + 2) * d.dv, d.vs + (size_t)(s + 1) * d.dv);
+        d.lw[m] = l;
+        lv[0] = l;
+    }
+    if (weight) {
+        float mx, sx;
+        block_lse_partial<1>(lv, xch[0], xch[1], mx, sx);
         if (threadIdx.x == 0) {
             d.bmax[blockIdx.x] = mx;
             d.bsumexp[blockIdx.x] = sx;
@@ -3360,6 +3470,22 @@ int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
         return FBSMI_OK;
     }
     LG_DISPATCH(s, (k_filt_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, f->u0s)));
+    // N a power of two with 2..256 tiles: the searches walk the summation tree, a step is two launches (no cdf)
+    const bool tree = s->tree_step && d.trW && s->items == 1;
+    if (tree) {
+        for (int k = 0; k < d.T; ++k) {
+            if (d.flow == 0)
+                LG_DISPATCH(s, (void)ITEMS; (k_filt_prop1t<DMAX><<<gtile, kBlock, 0, st>>>(d, k, k > 0, k > 0 ? k - 1 : 0, 1, 1)));
+            k_filt_norm<1, true><<<gtile, kBlock, 0, st>>>(d);
+            if (d.flow == 1)
+                LG_DISPATCH(s, (void)ITEMS; (k_filt_prop1t<DMAX><<<gtile, kBlock, 0, st>>>(d, k, 1, k, k + 1 < d.T ? 2 : 0, 1)));
+        }
+        if (d.flow == 0)
+            LG_DISPATCH(s, (void)ITEMS; (k_filt_prop1t<DMAX><<<gtile, kBlock, 0, st>>>(d, d.T, 1, d.T - 1, 0, 0)));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("filter launch: ") + hipGetErrorString(e));
+        return FBSMI_OK;
+    }
     for (int k = 0; k < d.T; ++k) {
         if (d.flow == 0)
             LG_DISPATCH(s, (k_filt_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k, k > 0, k > 0 ? k - 1 : 0, 1, 1)));

@@ -349,7 +349,9 @@ def test_sharded_module_world1_on_gpu(oracle, dev):
                                      (lambda: toy_gp(100), 100, 8),      # the reference's gp_filter / gp_pmcmc scale
                                      (lambda: toy_gp(33, 17), 37, 6),    # wide, odd sizes, tiles straddling du
                                      (lambda: toy_gp(20), 256, 5),
-                                     (lambda: toy_gp(20), 300, 5), (lambda: toy_gp(33, 17), 1000, 4)])   # several tiles
+                                     (lambda: toy_gp(20), 300, 5), (lambda: toy_gp(33, 17), 1000, 4),    # several tiles
+                                     # powers of two with 2..256 tiles: the TWO-launch filter step (tree-walking searches)
+                                     (toy_4d, 512, 6), (toy_2d, 4096, 8), (toy_2d, 65536, 3)])
 def test_fused_filters_match_oracle(toy, n, T, resampling, oracle, dev):
     """The fused (hipGraph) bootstrap_filter / pmcmc_filter_step of the analytic model, reached through
     the unchanged fbs_amd.samplers.smc signatures, against the oracle -- and against the closure tier."""
