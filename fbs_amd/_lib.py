@@ -29,19 +29,35 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: cannot build libfbsmi")
 
 
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in _DEPS)
+
+
 def build(force: bool = False) -> str:
-    """Compile libfbsmi.so for gfx950 if it is missing or older than its sources."""
+    """Compile libfbsmi.so for gfx950 if it is missing or older than its sources.  Safe when several processes call it at
+    once (the ranks of a multi-GPU launch): one builds under a file lock, into a temporary file that is renamed into place,
+    the others wait and find it fresh."""
     have_src = all(os.path.exists(p) for p in _DEPS)
-    stale = not os.path.exists(LIB_PATH)
-    if have_src and not stale:
-        t = os.path.getmtime(LIB_PATH)
-        stale = any(os.path.getmtime(p) > t for p in _DEPS)
-    if force or stale:
-        if not have_src:
-            raise RuntimeError("libfbsmi sources missing and no prebuilt library at " + LIB_PATH)
-        os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + _SRC
-        subprocess.check_call(cmd)
+    if not (force or _stale()):
+        return LIB_PATH
+    if not have_src:
+        if os.path.exists(LIB_PATH) and not force:
+            return LIB_PATH
+        raise RuntimeError("libfbsmi sources missing and no prebuilt library at " + LIB_PATH)
+    import fcntl
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or _stale():
+                tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+                subprocess.check_call([_hipcc()] + HIPCC_FLAGS + ["-o", tmp] + _SRC)
+                os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

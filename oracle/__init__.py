@@ -33,7 +33,13 @@ def build(force: bool = False) -> str:
     if force or stale:
         if not os.path.exists(src):
             raise RuntimeError("oracle source missing and no prebuilt libfbs_oracle.so")
-        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:   # several ranks may get here at once: one make at a time
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return _SO
 
 
