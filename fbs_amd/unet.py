@@ -211,7 +211,7 @@ def _w16_of(conv: nn.Conv2d):
 
 def _proj64_fusable(parts, cout) -> bool:
     chans = tuple(t.shape[1] for t in parts)
-    return (_MFMA_KERNELS and cout == 64 and chans in ((64,), (128,), (64, 64)) and not torch.is_grad_enabled()
+    return (_MFMA_KERNELS and os.environ.get("FBSMI_NN_PROJ64", "1") != "0" and cout == 64 and chans in ((64,), (128,), (64, 64)) and not torch.is_grad_enabled()
             and all(t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous(memory_format=torch.channels_last) for t in parts))
 
 
