@@ -184,8 +184,9 @@ def em_finish_roofline(dev):
             "frac": fbytes / fus / 1e3 / PEAK_HBM_GBS, "traffic": None,
             "concat_kernel": {"avg_launch_us": cus, "bytes_per_launch": cbytes, "achieved": cbytes / cus / 1e3,
                               "frac": cbytes / cus / 1e3 / PEAK_HBM_GBS},
-            "note": "the same box's torch copy_ of 100 MB cold buffers moves 5.1 TB/s = 0.64 of the 8 TB/s peak; the finish kernel "
-                    "also issues ~140 vector instructions per unobserved element (Threefry + erf_inv): see DESIGN.md section 5"}
+            "note": "the same box's torch copy_ of 100 MB cold buffers moves 5.1 TB/s = 0.64 of the 8 TB/s peak; the finish kernel's "
+                    "proposal and log-density roles queue on the same memory pipeline and their times add (with the normals "
+                    "pre-drawn it is no faster): see DESIGN.md section 5.0"}
 
 
 def sharded_leg(dev, dist, world, rank, nsteps):
