@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(64 * NW) k_conv3x3(const __hip_bfloat16* __res
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h2 = lane >> 5;
     const int npatch = kTile + 2 * W + 2, nchunk = npatch * 2 * CK;
-    constexpr int kMaxPer = NW == 8 ? 10 : 24;       // staged chunks per thread (host: nchunk <= kMaxPer * kThreads)
+    constexpr int kMaxPer = NW >= 6 ? 12 : 24;       // staged chunks per thread (host: nchunk <= kMaxPer * kThreads)
     // what does not change from tile to tile is worked out once: which chunk of the staged range a thread fetches (pixel
     // offset, element offset, LDS slot); pixel indices fit 32 bits (host check)
     int fdq[kMaxPer], foff[kMaxPer], fslot[kMaxPer];
@@ -956,12 +956,14 @@ extern "C" int fbsmi_nn_conv3x3(const void* x, int32_t xstride, const void* w, i
     const int nco = ck == 4 ? 64 : 32;               // output channels per workgroup: 72 KB of weights either way
     auto lds_of = [&](int nw, int mb) { return (size_t)16 * (9 * ck * 2 * nco + (size_t)(32 * mb * nw + 2 * W + 3) * (2 * ck + 1)); };
     auto fits = [&](int nw, int mb) {
-        return lds_of(nw, mb) <= 160 * 1024 && (long long)(32 * mb * nw + 2 * W + 2) * 2 * ck <= (nw == 8 ? 10ll * 512 : 24ll * 256);
+        return lds_of(nw, mb) <= 160 * 1024 &&
+               (long long)(32 * mb * nw + 2 * W + 2) * 2 * ck <= (nw >= 6 ? 12ll : 24ll) * 64 * nw;
     };
     int nw = 8, mb = 1;      // measured (tools/bench_conv.py): 8 waves x 32 pixels beats 8 x 64 and both 4-wave shapes
+    if (!fits(nw, mb)) nw = 6;   // (128-channel slices on 32-pixel rows miss the 8-wave tile by 1.3 KB of LDS)
     if (!fits(nw, mb)) nw = 4;
     if (const char* cfg = getenv("FBSMI_CONV_CFG")) { nw = cfg[0] - '0'; mb = cfg[1] - '0'; }
-    if ((nw != 4 && nw != 8) || (mb != 1 && mb != 2) || !fits(nw, mb))
+    if ((nw != 4 && nw != 6 && nw != 8) || (mb != 1 && mb != 2) || (nw == 6 && mb != 1) || !fits(nw, mb))
         return fail(FBSMI_ERR_UNSUPPORTED, "nn_conv3x3: image rows too wide for the staged range");
     const size_t lds = lds_of(nw, mb);
     const int tile = 32 * mb * nw;
@@ -980,11 +982,13 @@ extern "C" int fbsmi_nn_conv3x3(const void* x, int32_t xstride, const void* w, i
     if (ck == 4) {
         if (nw == 8 && mb == 2) FBSMI_CONV_LAUNCH(4, 2, 8, 2)
         else if (nw == 8) FBSMI_CONV_LAUNCH(4, 2, 8, 1)
+        else if (nw == 6) FBSMI_CONV_LAUNCH(4, 2, 6, 1)
         else if (mb == 2) FBSMI_CONV_LAUNCH(4, 2, 4, 2)
         else FBSMI_CONV_LAUNCH(4, 2, 4, 1)
     } else {
         if (nw == 8 && mb == 2) FBSMI_CONV_LAUNCH(8, 1, 8, 2)
         else if (nw == 8) FBSMI_CONV_LAUNCH(8, 1, 8, 1)
+        else if (nw == 6) FBSMI_CONV_LAUNCH(8, 1, 6, 1)
         else if (mb == 2) FBSMI_CONV_LAUNCH(8, 1, 4, 2)
         else FBSMI_CONV_LAUNCH(8, 1, 4, 1)
     }

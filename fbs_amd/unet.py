@@ -172,10 +172,11 @@ def _conv3x3_fusable(x, weight, stride=(1, 1), padding=(1, 1)) -> bool:
         if not (t.dtype == torch.bfloat16 and t.shape[1] % 64 == 0 and t.shape[0] == x0.shape[0] and t.shape[2:] == x0.shape[2:]
                 and t.is_contiguous(memory_format=torch.channels_last)):
             return False
-    # where it beats MIOpen (tools/bench_conv.py): every 64-channel slice (1.6-2.3x), 128-channel slices when the output is
-    # 64 channels wide or the rows are short enough for the 8-wave tile (1.1-2.4x); wide rows x wide outputs stay with MIOpen
+    # where it beats MIOpen (tools/bench_conv.py): every 64-channel slice (1.6-2.5x), 128-channel slices when the output is
+    # 64 channels wide or the rows are short enough for the 8- or 6-wave tile (1.1-2.4x); wider rows x wide outputs stay
+    # with MIOpen
     wide = any(t.shape[1] >= 128 for t in parts)
-    return (not wide) or weight.shape[0] == 64 or x0.shape[3] <= 28
+    return (not wide) or weight.shape[0] == 64 or x0.shape[3] <= 32
 
 
 def _conv3x3_hip(x, w16, bias):
