@@ -480,7 +480,10 @@ def _conv_pixel_shuffle(conv: nn.Conv2d, x, scale: int):
     if not (x.is_cuda and not torch.is_grad_enabled() and c % 8 == 0):
         return pixel_shuffle_nhwc(conv(x), scale)
     from . import _lib
-    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+    if _conv3x3_fusable(x, conv.weight, conv.stride, conv.padding) and x.shape[1] <= 128:   # (two slices x 1024 outputs: MIOpen's)
+        y = _conv3x3_hip(x, _w16_of(conv), None)
+    else:
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
     dt = _kernel_dtype(y)
     if dt is None:
         return pixel_shuffle_nhwc(_add_bias(y, conv.bias) if conv.bias is not None else y, scale)
