@@ -444,7 +444,10 @@ class AttnBlock(nn.Module):
     def forward(self, x):
         if self.linear:
             return self.attn(self.norm(x), residual=x)     # the skip connection rides on the output norm's kernel
-        return self.attn(self.norm(x)) + x
+        y = self.attn(self.norm(x)) + x
+        if x.is_cuda and x.dtype != torch.float32 and not torch.is_grad_enabled():
+            y = y.contiguous(memory_format=torch.channels_last)   # (the full attention's reshape leaves NCHW: keep the network NHWC)
+        return y
 
 
 def _kernel_dtype(x):
