@@ -102,7 +102,9 @@ def gp100_leg(dev):
 def image_legs(dev, nsteps):
     """Configs 3-5 in shape (fbs_amd/image_configs.py: synthetic image, random-init UNet dim 64, bf16): one
     gibbs_kernel sweep of `nsteps` of the configuration's steps on this GPU's share of the particles, network time
-    (torch events around every network call) and sampler time (everything else) apart."""
+    (torch events around every network call) and sampler time (everything else) apart.  `ms_per_step` = the timed sweep
+    divided by its steps (it carries the sweep's fixed parts: with 6 steps, explicit_final's initial weights alone are a
+    seventh network evaluation); `ms_per_step_marginal` = what one more step costs."""
     from fbs_amd import image_configs, ops
     out = {}
     for name, label in (("c3", "c3"), ("c4", "c4_shard"), ("c5", "c5_shard")):
@@ -120,12 +122,26 @@ def image_legs(dev, nsteps):
         pr = c.sb.profile
         ev = lambda a, b: sum(x.elapsed_time(y) for x, y in zip(pr[a], pr[b])) / max(1, len(pr[a])) * 1e3
         full = image_configs.CONFIGS[name]
+        # a sweep has fixed parts (explicit_final's initial weights are one more network evaluation, the forward path, the
+        # final move): the MARGINAL step is the difference between two sweeps of different length
+        marginal = None
+        if nsteps >= 4:
+            ns2 = max(1, nsteps // 3)
+            c2 = image_configs.make(name, dev, dtype="bf16", nsteps=ns2)
+            image_configs.gibbs_sweep(c2, ops.PRNGKey(3), n)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            image_configs.gibbs_sweep(c2, ops.PRNGKey(4), n)
+            torch.cuda.synchronize(dev)
+            marginal = (dt - (time.perf_counter() - t1)) / (nsteps - ns2) * 1e3
+            del c2
         out[label] = {"workload": f"{full['task']} on {full['image']}, UNet dim 64 random init bf16, {n} particles on this GPU "
                                   f"(+1: explicit_final; ensemble {full['nparticles']} over {full['ngpus']} GPU(s)), "
                                   f"{nsteps} of the configuration's {full['nsteps']} steps timed",
                       "ms_per_step": dt / nsteps * 1e3, "network_ms_per_step": net_ms / nsteps,
                       "sampler_ms_per_step": (dt * 1e3 - net_ms) / nsteps, "particle_steps_per_s": n * nsteps / dt,
-                      "full_sweep_s_extrapolated": dt / nsteps * full["nsteps"],
+                      "ms_per_step_marginal": marginal,
+                      "full_sweep_s_extrapolated": (dt + (marginal if marginal else dt / nsteps * 1e3) * 1e-3 * (full["nsteps"] - nsteps)),
                       "concat_kernel_us_with_event_overhead": ev("concat0", "concat1"),
                       "finish_kernel_us_with_event_overhead": ev("finish0", "finish1")}
         del c
