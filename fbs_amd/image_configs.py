@@ -26,14 +26,16 @@ from .unet import UNet
 
 CONFIGS = {
     "c3": dict(task="inpaint-15", image=(28, 28, 1), T=2.0, nsteps=1000, nparticles=4096, ngpus=1, mode="score",
-               ef=True, chunk=1024),
+               ef=True, chunk=4096),
     "c4": dict(task="supr-4", image=(28, 28, 1), T=0.5, nsteps=50, nparticles=8192, ngpus=4, mode="drift", ef=True,
-               chunk=1024),
+               chunk=2048),
     "c5": dict(task="inpaint-32", image=(64, 64, 3), T=2.0, nsteps=1000, nparticles=16384, ngpus=8, mode="score",
-               ef=True, chunk=512),
+               ef=True, chunk=2048),
 }
-# chunk = rows per network call.  Power-of-two chunks keep MIOpen on kernels it ships: one call of 4097 / 2049 rows is 8 % faster
-# per step (config 3: 87 ms against 95; config 5: 169 against 183) but costs a fresh machine 50-120 s of kernel builds first.
+# chunk = rows per network call: the whole shard in one power-of-two call plus explicit_final's one-row tail.  Power-of-two
+# chunks keep MIOpen on kernels it ships (one call of 4097 / 2049 rows cost a fresh machine 50-120 s of kernel builds); with
+# most of the network on this library's persistent-tile kernels bigger calls pay: config 3 43.7 / 39.9 / 38.3 ms per step at
+# chunks of 1024 / 2048 / 4096, config 5's share 94.2 / 86.9 / 84.4 ms at 512 / 1024 / 2048 (tools/bench_images.py, one box).
 
 
 def make(name: str, device, dtype: str = "bf16", nsteps: int | None = None, dim: int = 64, seed: int = 996,
