@@ -50,7 +50,7 @@ def main(argv=None):
     p.add_argument('--marg', action='store_true', default=False, help='Whether marginalise out the Y path.')
     p.add_argument('--dim', type=int, default=64, help='UNet width (64 in the reference).')
     p.add_argument('--fp32', action='store_true', help='float32 network instead of bf16 autocast.')
-    p.add_argument('--chunk', type=int, default=1024, help='Particles per network call.')
+    p.add_argument('--chunk', type=int, default=4096, help='Particles per network call (a power of two: MIOpen ships kernels for those batch sizes; bigger calls are faster per particle).')
     p.add_argument('--outdir', type=str, default='./imgs/results')
     p.add_argument('--quiet', action='store_true')
     args = p.parse_args(argv)
