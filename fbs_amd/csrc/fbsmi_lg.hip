@@ -1838,13 +1838,19 @@ template <int KIND>
 __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, int nrt, int Kp, int S, int emit, int kres) {
     constexpr bool FUSED = KIND == 1;
     constexpr bool FILT = KIND >= 2;
+    // KIND 1 with kres >= 8 (kres is otherwise unused there): the grid is eight times as wide and only every eighth block
+    // works -- blocks b and b + 8 share an XCD, so the whole small ensemble runs on ONE XCD and what a step hands to the next
+    // (log-density terms, particles, noise) is found in that XCD's L2 instead of behind the fabric.
+    const bool pin = KIND == 1 && kres >= 8;   // kres - 8 = which of the eight classes of blocks (chains take different ones)
+    if (pin && (int)(blockIdx.x & 7) != kres - 8) return;
+    const int bx = pin ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, gx = pin ? (int)(gridDim.x >> 3) : (int)gridDim.x;
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ LgwPreLds pre;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* Gs = dyn;                    // [32 rows][S]: rows 32*tr .. of G_s
     float* Zs = dyn + kWideTile * S;    // [32 slots][S]: z = (u[ancestor], v_prev)
     const int N = d.N, du = d.du, D = d.D;
-    const int ts = blockIdx.x / nrt, tr = tr0 + (blockIdx.x - ts * nrt);
+    const int ts = bx / nrt, tr = tr0 + (bx - ts * nrt);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t* kt = d.keytab + 8 * s;
     const uint32_t t0 = kt[FILT ? 0 : 6], t1 = kt[FILT ? 1 : 7];   // key_transition (Gibbs) / key_proposal (filters)
@@ -1933,8 +1939,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
         }
     };
     if (KIND == 1 || KIND == 2) {   // the G tile is on its way; now the step's ancestors, worked out by this workgroup itself
-        if (KIND == 1) lgw_pre_body<true>(d, s, blockIdx.x == 0, pre, fetch_noise);
-        else lgw_fpre_body<true>(d, kres, blockIdx.x == 0, pre, draw_noise);
+        if (KIND == 1) lgw_pre_body<true>(d, s, bx == 0, pre, fetch_noise);
+        else lgw_fpre_body<true>(d, kres, bx == 0, pre, draw_noise);
 #pragma unroll
         for (int jj = 0; jj < kRows; ++jj) {
             const int mj = kWideTile * ts + wave + kWaves * jj;
@@ -2028,8 +2034,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     if (KIND == 1 && (s + 1 < d.T || stamp_tail)) {   // this workgroup's share of the next step's noise
         const int sn = s + 1 < d.T ? s + 1 : s;
         const uint32_t n0 = d.keytab[8 * sn + 6], n1 = d.keytab[8 * sn + 7];
-        const int total = N * du, per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
-        const int e0 = (int)blockIdx.x * per, e1 = e0 + per < total ? e0 + per : total;
+        const int total = N * du, per = (total + gx - 1) / gx;
+        const int e0 = bx * per, e1 = e0 + per < total ? e0 + per : total;
         for (int e = e0 + t; e < e1; e += kBlock) d.xiw[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
     }
     FBSMI_STAMP(24)
@@ -2930,7 +2936,12 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     if (persistent) LG_DISPATCH(s, (void)ITEMS; (k_lg_sweep1<DMAX><<<gone, kBlock, 0, st>>>(d)));
     for (int k = 0; one_tile && !persistent && k < d.T; ++k) {
         ProfScope p(s, 2, st);
-        if (d.wide) k_lgw_gemm<1><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
+        if (d.wide) {
+            static const int pin = [] { const char* e = getenv("FBSMI_WIDE_PIN"); return e ? atoi(e) : 1; }();
+            if (pin && d.C == 1 && gwide.x <= 32)
+                k_lgw_gemm<1><<<dim3(gwide.x * 8, 1), kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 8 + ((2 * d.c0) & 7));
+            else k_lgw_gemm<1><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
+        }
         else LG_DISPATCH(s, (void)ITEMS; (k_lg_step1<DMAX><<<gone, kBlock, 0, st>>>(d, k)));
     }
     if (one_tile) {   // log-weights / tile partial for the final-mode kernels
