@@ -50,6 +50,8 @@ constexpr int kNumProfKernels = 3; // norm, cdf, prop
 struct LgDev {
     int C;           // independent chains batched in every launch (blockIdx.y): jax.vmap over chains
     int Ctot, c0;    // this handle drives chains c0 .. c0 + C - 1 of a batch of Ctot (fbsmi_lg_sweep_set_group; default C, 0)
+    int pin;         // small ensembles: the two-launch step's grids are 8x as wide and only every eighth block works, so the
+                     // whole step runs on ONE XCD (blocks b and b + 8 share one) and its hand-offs stay in that XCD's L2
     int N;           // rows of the particle system (nparticles, +1 when explicit_final)
     int nparticles;
     int du, dv, D, T;
@@ -470,10 +472,15 @@ __device__ __forceinline__ float tree_left_sum(const TreePath p, int i) {   // b
 
 template <int ITEMS, int MODE, bool PUB = false>
 __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
+    int bx = blockIdx.x;
+    if (PUB && dd.pin) {
+        if (blockIdx.x & 7) return;
+        bx = blockIdx.x >> 3;
+    }
     const LgDev d = chain_view(dd, blockIdx.y);
     if (MODE == 0) { FBSMI_STAMP(2) }
     __shared__ float xch[4][4];
-    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    const int base = (bx * kBlock + threadIdx.x) * ITEMS;
     const int i_ref = d.bs[MODE == 0 ? s : d.T];
     float l[ITEMS];
 #pragma unroll
@@ -511,15 +518,15 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
         if ((i & 3) == 0) {   // the midpoints of the nodes of 8 leaves and more: 64 threads, 16 per wave
             const int h = i ? tree_mid_node(i) : 0;
             const float2 node = make_float2(i ? tree_left_sum(p2[0], i) : 0.0f, xw[0]);
-            d.trW[(size_t)blockIdx.x * kTreeNodes + h] = node;
-            if (h < kMidN) d.trWtop[blockIdx.x * kMidN + h] = node;
-            if (i == 0) d.wfirst[blockIdx.x] = node.y;
+            d.trW[(size_t)bx * kTreeNodes + h] = node;
+            if (h < kMidN) d.trWtop[bx * kMidN + h] = node;
+            if (i == 0) d.wfirst[bx] = node.y;
         }
     }
     if (threadIdx.x == 0) {
-        if (MODE != 1) d.bsumw[blockIdx.x] = t2[0];
-        if (MODE != 2) d.bsumJ[blockIdx.x] = t2[1];
-        if (blockIdx.x == 0) {
+        if (MODE != 1) d.bsumw[bx] = t2[0];
+        if (MODE != 2) d.bsumJ[bx] = t2[1];
+        if (bx == 0) {
             d.scal[0] = lse;
             d.scal[1] = w_max;
             d.scal[2] = w_k;
@@ -1082,7 +1089,12 @@ __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) 
     __shared__ float lastsh;
     FBSMI_STAMP(6)
     const int N = d.N, tid = threadIdx.x & (kBlock - 1), half = threadIdx.x / kBlock;
-    const int tileb = blockIdx.x * HALVES + half;
+    int bx = blockIdx.x;
+    if (dd.pin) {   // (pinned launches use HALVES == 1)
+        if (blockIdx.x & 7) return;
+        bx = blockIdx.x >> 3;
+    }
+    const int tileb = bx * HALVES + half;
     const uint32_t* kt = d.keytab + 8 * s;
     const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], t0 = kt[6], t1 = kt[7];
     const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
@@ -2957,7 +2969,7 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     for (int k = 0; !one_tile && k < d.T; ++k) {
         if (s->debug_mask & 1) {
             ProfScope p(s, 0, st);
-            if (tree) k_lg_norm<1, 0, true><<<gtile, kBlock, 0, st>>>(d, k);
+            if (tree) k_lg_norm<1, 0, true><<<dim3(gtile.x * (d.pin ? 8 : 1), d.C), kBlock, 0, st>>>(d, k);
             else LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 0><<<gtile, kBlock, 0, st>>>(d, k)));
         }
         if ((s->debug_mask & 2) && !tree) {
@@ -2984,7 +2996,7 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                 // -1 % for a single chain, which keeps one tile per workgroup)
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1t<DMAX, 2><<<dim3(nb / 2, d.C), 2 * kBlock, 0, st>>>(d, k)));
             } else if (tree) {
-                LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1t<DMAX, 1><<<gtile, kBlock, 0, st>>>(d, k)));
+                LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1t<DMAX, 1><<<dim3(gtile.x * (d.pin ? 8 : 1), d.C), kBlock, 0, st>>>(d, k)));
             } else if (two_slot) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
             } else if (s->items == 1 && !s->generic_prop) {
@@ -3178,6 +3190,11 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         rc |= slab_request(s, &d.trW, C * (size_t)kTreeNodes * d.nb);
         rc |= slab_request(s, &d.trWtop, C * (size_t)kMidN * d.nb);
         rc |= slab_request(s, &d.wfirst, C * (size_t)d.nb);
+        // few workgroups per launch (BASELINE config 1: 4 tiles): keep the step on one XCD.  Only with the default kernel
+        // choices (one tile per workgroup, one slot per thread), which is what such sizes get.  FBSMI_PIN=0 turns it off.
+        const char* pe = getenv("FBSMI_PIN");
+        d.pin = (s->tree_step && !s->generic_prop && s->tree_halves < 0 && s->two_slot_prop < 0 && (int64_t)d.nb * C <= 32 &&
+                 !(pe && atoi(pe) == 0)) ? 1 : 0;
     }
     rc |= slab_request(s, &d.bsumw, C * d.nb);
     rc |= slab_request(s, &d.bsumJ, C * d.nb);
