@@ -3190,11 +3190,13 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         rc |= slab_request(s, &d.trW, C * (size_t)kTreeNodes * d.nb);
         rc |= slab_request(s, &d.trWtop, C * (size_t)kMidN * d.nb);
         rc |= slab_request(s, &d.wfirst, C * (size_t)d.nb);
-        // few workgroups per launch (BASELINE config 1: 4 tiles): keep the step on one XCD.  Only with the default kernel
+        // few workgroups per launch (BASELINE config 1: 4 tiles; up to 64 workgroups): keep the step on one XCD.  Only with the default kernel
         // choices (one tile per workgroup, one slot per thread), which is what such sizes get.  FBSMI_PIN=0 turns it off.
         const char* pe = getenv("FBSMI_PIN");
-        d.pin = (s->tree_step && !s->generic_prop && s->tree_halves < 0 && s->two_slot_prop < 0 && (int64_t)d.nb * C <= 32 &&
-                 !(pe && atoi(pe) == 0)) ? 1 : 0;
+        const char* pm = getenv("FBSMI_PIN_MAX");   // (diagnostic: workgroups per launch up to which the step is pinned)
+        const int64_t pin_max = pm ? atoi(pm) : 64;   // two workgroups per CU of the XCD: measured better up to there, worse beyond
+        d.pin = (s->tree_step && !s->generic_prop && s->tree_halves < 0 && s->two_slot_prop < 0 && (int64_t)d.nb * C <= pin_max &&
+                 (int64_t)d.nb * C < 2 * 256 && !(pe && atoi(pe) == 0)) ? 1 : 0;
     }
     rc |= slab_request(s, &d.bsumw, C * d.nb);
     rc |= slab_request(s, &d.bsumJ, C * d.nb);
