@@ -2487,9 +2487,14 @@ __global__ void __launch_bounds__(kBlock) k_filt_init(LgDev dd, const float* u0s
 // fnorm: c = logsumexp(lw); accumulate the (negative) log-likelihood; w = exp(lw - c); partials
 template <int ITEMS, bool PUB = false>   // PUB: publish the tile's part of the summation tree (two-launch filter step)
 __global__ void __launch_bounds__(kBlock) k_filt_norm(LgDev dd) {
+    int bx = blockIdx.x;
+    if (PUB && dd.pin) {   // small ensembles: every eighth block works (one XCD), see LgDev.pin
+        if (blockIdx.x & 7) return;
+        bx = blockIdx.x >> 3;
+    }
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float xch[3][4];
-    const int base = (blockIdx.x * kBlock + threadIdx.x) * ITEMS;
+    const int base = (bx * kBlock + threadIdx.x) * ITEMS;
     float l[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) l[i] = base + i < d.N ? d.lw[base + i] : 0.0f;
@@ -2514,14 +2519,14 @@ __global__ void __launch_bounds__(kBlock) k_filt_norm(LgDev dd) {
         if ((i & 3) == 0) {
             const int h = i ? tree_mid_node(i) : 0;
             const float2 node = make_float2(i ? tree_left_sum(p1[0], i) : 0.0f, xw[0]);
-            d.trW[(size_t)blockIdx.x * kTreeNodes + h] = node;
-            if (h < kMidN) d.trWtop[blockIdx.x * kMidN + h] = node;
-            if (i == 0) d.wfirst[blockIdx.x] = node.y;
+            d.trW[(size_t)bx * kTreeNodes + h] = node;
+            if (h < kMidN) d.trWtop[bx * kMidN + h] = node;
+            if (i == 0) d.wfirst[bx] = node.y;
         }
     }
     if (threadIdx.x == 0) {
-        d.bsumw[blockIdx.x] = t1[0];
-        if (blockIdx.x == 0) {
+        d.bsumw[bx] = t1[0];
+        if (bx == 0) {
             const float e0 = *d.ell;
             *d.ell = d.flow == 0 ? e0 - (c - d.logn)      // log_nell -= _c - log(N)          smc.py:67
                                  : (e0 - d.logn) + c;      // log_ell = log_ell - log(N) + _c  smc.py:146
@@ -2626,6 +2631,11 @@ __global__ void __launch_bounds__(kBlock) k_filt_prop(LgDev dd, int s, int resam
 // four leaves of w in two round trips.  Same flags and arithmetic as k_filt_prop<1, DMAX>.
 template <int DMAX>
 __global__ void __launch_bounds__(kBlock) k_filt_prop1t(LgDev dd, int s, int resample, int kres, int weight, int propagate) {
+    int bx = blockIdx.x;
+    if (dd.pin) {
+        if (blockIdx.x & 7) return;
+        bx = blockIdx.x >> 3;
+    }
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float xch[3][4];
     __shared__ __attribute__((aligned(16))) float2 topW[kBlock];
@@ -2656,7 +2666,7 @@ __global__ void __launch_bounds__(kBlock) k_filt_prop1t(LgDev dd, int s, int res
     const int st = s < d.T ? s : d.T - 1;
     const StepTables<DMAX> t = step_tables<DMAX>(d, st);
     const StepTables<DMAX> tn = step_tables<DMAX>(d, st + 1 < d.T ? st + 1 : st);
-    const int m = blockIdx.x * kBlock + tid;   // N is a multiple of the tile: every slot is live
+    const int m = bx * kBlock + tid;   // N is a multiple of the tile: every slot is live
     float lv[1] = {-__builtin_inff()};
     int a = m;
     if (resample) {   // _systematic_or_stratified, resampling.py:43-51
@@ -2714,8 +2724,8 @@ __global__ void __launch_bounds__(kBlock) k_filt_prop1t(LgDev dd, int s, int res
         float mx, sx;
         block_lse_partial<1>(lv, xch[0], xch[1], mx, sx);
         if (threadIdx.x == 0) {
-            d.bmax[blockIdx.x] = mx;
-            d.bsumexp[blockIdx.x] = sx;
+            d.bmax[bx] = mx;
+            d.bsumexp[bx] = sx;
         }
     }
 }
@@ -3503,15 +3513,16 @@ int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
     // N a power of two with 2..256 tiles: the searches walk the summation tree, a step is two launches (no cdf)
     const bool tree = s->tree_step && d.trW && s->items == 1;
     if (tree) {
+        const dim3 gpin(gtile.x * (d.pin ? 8 : 1), d.C);   // (pinned to one XCD when the launches are small: LgDev.pin)
         for (int k = 0; k < d.T; ++k) {
             if (d.flow == 0)
-                LG_DISPATCH(s, (void)ITEMS; (k_filt_prop1t<DMAX><<<gtile, kBlock, 0, st>>>(d, k, k > 0, k > 0 ? k - 1 : 0, 1, 1)));
-            k_filt_norm<1, true><<<gtile, kBlock, 0, st>>>(d);
+                LG_DISPATCH(s, (void)ITEMS; (k_filt_prop1t<DMAX><<<gpin, kBlock, 0, st>>>(d, k, k > 0, k > 0 ? k - 1 : 0, 1, 1)));
+            k_filt_norm<1, true><<<gpin, kBlock, 0, st>>>(d);
             if (d.flow == 1)
-                LG_DISPATCH(s, (void)ITEMS; (k_filt_prop1t<DMAX><<<gtile, kBlock, 0, st>>>(d, k, 1, k, k + 1 < d.T ? 2 : 0, 1)));
+                LG_DISPATCH(s, (void)ITEMS; (k_filt_prop1t<DMAX><<<gpin, kBlock, 0, st>>>(d, k, 1, k, k + 1 < d.T ? 2 : 0, 1)));
         }
         if (d.flow == 0)
-            LG_DISPATCH(s, (void)ITEMS; (k_filt_prop1t<DMAX><<<gtile, kBlock, 0, st>>>(d, d.T, 1, d.T - 1, 0, 0)));
+            LG_DISPATCH(s, (void)ITEMS; (k_filt_prop1t<DMAX><<<gpin, kBlock, 0, st>>>(d, d.T, 1, d.T - 1, 0, 0)));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("filter launch: ") + hipGetErrorString(e));
         return FBSMI_OK;

@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 T = 200
 ts = np.linspace(0.0, 2.0, T + 1)
 br = fbs_amd.LinearGaussianBridge(np.array([-1.0, 1.0]), np.array([[2.0, 0.4], [0.4, 0.5]]), StationaryConstLinearSDE(a=-0.5, b=1.0), ts, du=1, device=dev)
-for N in (65536, 70000):
+for N in (4096, 65536, 70000):
     for flow in ("bootstrap", "pmcmc"):
         h = br.filter_handle(N, flow, "stratified")
         vs = torch.zeros((T + 1, 1), device=dev)
