@@ -1853,8 +1853,9 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     // KIND 1 with kres >= 8 (kres is otherwise unused there): the grid is eight times as wide and only every eighth block
     // works -- blocks b and b + 8 share an XCD, so the whole small ensemble runs on ONE XCD and what a step hands to the next
     // (log-density terms, particles, noise) is found in that XCD's L2 instead of behind the fabric.
-    const bool pin = KIND == 1 && kres >= 8;   // kres - 8 = which of the eight classes of blocks (chains take different ones)
-    if (pin && (int)(blockIdx.x & 7) != kres - 8) return;
+    // (the filters' launches, whose kres is a step index, ask for it with bit 8 of `emit`: class 0)
+    const bool pin = (KIND == 1 && kres >= 8) || (KIND != 1 && (emit & 0x100));
+    if (pin && (int)(blockIdx.x & 7) != (KIND == 1 ? kres - 8 : 0)) return;
     const int bx = pin ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, gx = pin ? (int)(gridDim.x >> 3) : (int)gridDim.x;
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ LgwPreLds pre;
@@ -3489,20 +3490,24 @@ int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
             if (e != hipSuccess) return fail(FBSMI_ERR_HIP, std::string("filter launch: ") + hipGetErrorString(e));
             return FBSMI_OK;
         }
+        // one-tile ensembles: a step's launches are a few dozen workgroups -- pinned to one XCD (bit 8 of `emit`, grids 8x wide)
+        static const int pin_on = [] { const char* e = getenv("FBSMI_WIDE_PIN"); return e ? atoi(e) : 1; }();
+        const bool pinw = pin_on && d.C == 1 && nst * nrt <= 32;
+        const int pe = pinw ? 0x100 : 0, pg = pinw ? 8 : 1;
         if (d.flow == 0) {
             for (int k = 0; k < d.T; ++k) {
-                if (k == 0) k_lgw_gemm<3><<<dim3(nst * nrt, d.C), kBlock, lds, st>>>(d, k, 0, nrt, Kp, S, 3, 0);
-                else k_lgw_gemm<2><<<dim3(nst * nrt, d.C), kBlock, lds, st>>>(d, k, 0, nrt, Kp, S, 3, k - 1);
+                if (k == 0) k_lgw_gemm<3><<<dim3(nst * nrt * pg, d.C), kBlock, lds, st>>>(d, k, 0, nrt, Kp, S, 3 | pe, 0);
+                else k_lgw_gemm<2><<<dim3(nst * nrt * pg, d.C), kBlock, lds, st>>>(d, k, 0, nrt, Kp, S, 3 | pe, k - 1);
             }
             k_lgwf_final<<<gone, kBlock, 0, st>>>(d);
         } else {
             // weight the current particles (rows >= du, no resampling), then resample + propagate (rows < du)
-            k_lgw_gemm<3><<<dim3(nst * (nrt - v_tile0), d.C), kBlock, lds, st>>>(d, 0, v_tile0, nrt - v_tile0, Kp, S, 2, 0);
+            k_lgw_gemm<3><<<dim3(nst * (nrt - v_tile0) * pg, d.C), kBlock, lds, st>>>(d, 0, v_tile0, nrt - v_tile0, Kp, S, 2 | pe, 0);
             for (int k = 0; k < d.T; ++k) {
-                k_lgw_gemm<2><<<dim3(nst * u_tiles, d.C), kBlock, lds, st>>>(d, k, 0, u_tiles, Kp, S, 1, k);
+                k_lgw_gemm<2><<<dim3(nst * u_tiles * pg, d.C), kBlock, lds, st>>>(d, k, 0, u_tiles, Kp, S, 1 | pe, k);
                 if (k + 1 < d.T)
-                    k_lgw_gemm<3><<<dim3(nst * (nrt - v_tile0), d.C), kBlock, lds, st>>>(d, k + 1, v_tile0, nrt - v_tile0, Kp,
-                                                                                          S, 2, 0);
+                    k_lgw_gemm<3><<<dim3(nst * (nrt - v_tile0) * pg, d.C), kBlock, lds, st>>>(d, k + 1, v_tile0, nrt - v_tile0,
+                                                                                               Kp, S, 2 | pe, 0);
             }
         }
         hipError_t e = hipGetLastError();
