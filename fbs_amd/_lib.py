@@ -89,6 +89,7 @@ SIGNATURES = {
     "fbsmi_sum": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "fbsmi_logsumexp": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "fbsmi_normalise": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp, _vp]),
+    "fbsmi_normalise_ess": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "fbsmi_searchsorted": (C.c_int, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "fbsmi_resample": (C.c_int, [C.c_int, _vp, _u32, _u32, _i32, _vp, _vp, _vp]),
     "fbsmi_cond_resample": (C.c_int, [C.c_int, _u32, _u32, _vp, _i32, _i32, C.c_int, _i32, _vp, _vp, _vp]),
@@ -125,6 +126,7 @@ SIGNATURES = {
     "fbsmi_nn_linear_attention": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp]),
     "fbsmi_nn_qkv_linear_attention": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "fbsmi_nn_conv3x3": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "fbsmi_nn_conv3x3_supported": (C.c_int, [_i32, _i32, _i32, _i32]),   # a 0 / 1 answer, not a status: use lib() directly
     "fbsmi_nn_proj64": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _f, _vp, _vp, _i64, _vp]),
     "fbsmi_nn_channel_layernorm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _vp, _f, _vp, _vp, _vp]),
     "fbsmi_nn_groupnorm_silu": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

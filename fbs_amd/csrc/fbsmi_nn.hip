@@ -939,6 +939,35 @@ extern "C" int fbsmi_nn_qkv_linear_attention(const void* xn, const void* w, void
     return FBSMI_OK;
 }
 
+namespace {
+// Tile shape of k_conv3x3 for rows of W pixels and slices of Cin channels: 8 waves per workgroup when the staged range fits
+// beside the weights (72 KB) in 160 KB of LDS, else 6, else 4; a wave multiplies 32 pixels (or 64: two accumulator rows
+// sharing every weight fragment).  FBSMI_CONV_CFG=<waves><pixel blocks> overrides (diagnostic).  false: rows too wide.
+struct ConvShape { int nw, mb; size_t lds; };
+bool conv3x3_shape(int W, int Cin, ConvShape& out) {
+    const int ck = Cin / 16;
+    const int nco = ck == 4 ? 64 : 32;               // output channels per workgroup: 72 KB of weights either way
+    auto lds_of = [&](int nw, int mb) { return (size_t)16 * (9 * ck * 2 * nco + (size_t)(32 * mb * nw + 2 * W + 3) * (2 * ck + 1)); };
+    auto fits = [&](int nw, int mb) {
+        return lds_of(nw, mb) <= 160 * 1024 &&
+               (long long)(32 * mb * nw + 2 * W + 2) * 2 * ck <= (nw >= 6 ? 12ll : 24ll) * 64 * nw;
+    };
+    int nw = 8, mb = 1;      // measured (tools/bench_conv.py): 8 waves x 32 pixels beats 8 x 64 and both 4-wave shapes
+    if (!fits(nw, mb)) nw = 6;   // (128-channel slices on 32-pixel rows miss the 8-wave tile by 1.3 KB of LDS)
+    if (!fits(nw, mb)) nw = 4;
+    if (const char* cfg = getenv("FBSMI_CONV_CFG")) { nw = cfg[0] - '0'; mb = cfg[1] - '0'; }
+    if ((nw != 4 && nw != 6 && nw != 8) || (mb != 1 && mb != 2) || (nw == 6 && mb != 1) || !fits(nw, mb)) return false;
+    out = ConvShape{nw, mb, lds_of(nw, mb)};
+    return true;
+}
+}  // namespace
+
+extern "C" int fbsmi_nn_conv3x3_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    if (H < 1 || W < 1 || (Cin != 64 && Cin != 128) || Cout < 64 || Cout % 64 != 0) return 0;
+    ConvShape sh;
+    return conv3x3_shape(W, Cin, sh) ? 1 : 0;
+}
+
 extern "C" int fbsmi_nn_conv3x3(const void* x, int32_t xstride, const void* w, int32_t wstride, int32_t ci_off, const float* bias,
                                 void* y, int accumulate, int64_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream) {
     if (!x || !w || !y || B < 0 || H < 1 || W < 1 || xstride < Cin || xstride % 8 != 0 || ci_off < 0 || ci_off % 8 != 0 ||
@@ -950,22 +979,12 @@ extern "C" int fbsmi_nn_conv3x3(const void* x, int32_t xstride, const void* w, i
     const long long npix = (long long)B * H * W;
     if (npix > 0x3fffffff) return fail(FBSMI_ERR_UNSUPPORTED, "nn_conv3x3: more than 2^30 pixels per call");
     const int ck = Cin / 16;
-    // 8 waves per workgroup when the staged range fits beside the weights (72 KB) in 160 KB of LDS, else 4; a wave multiplies
-    // 32 pixels (or 64: two accumulator rows sharing every weight fragment).  FBSMI_CONV_CFG=<waves><pixel blocks> overrides
-    // (diagnostic).
-    const int nco = ck == 4 ? 64 : 32;               // output channels per workgroup: 72 KB of weights either way
-    auto lds_of = [&](int nw, int mb) { return (size_t)16 * (9 * ck * 2 * nco + (size_t)(32 * mb * nw + 2 * W + 3) * (2 * ck + 1)); };
-    auto fits = [&](int nw, int mb) {
-        return lds_of(nw, mb) <= 160 * 1024 &&
-               (long long)(32 * mb * nw + 2 * W + 2) * 2 * ck <= (nw >= 6 ? 12ll : 24ll) * 64 * nw;
-    };
-    int nw = 8, mb = 1;      // measured (tools/bench_conv.py): 8 waves x 32 pixels beats 8 x 64 and both 4-wave shapes
-    if (!fits(nw, mb)) nw = 6;   // (128-channel slices on 32-pixel rows miss the 8-wave tile by 1.3 KB of LDS)
-    if (!fits(nw, mb)) nw = 4;
-    if (const char* cfg = getenv("FBSMI_CONV_CFG")) { nw = cfg[0] - '0'; mb = cfg[1] - '0'; }
-    if ((nw != 4 && nw != 6 && nw != 8) || (mb != 1 && mb != 2) || (nw == 6 && mb != 1) || !fits(nw, mb))
-        return fail(FBSMI_ERR_UNSUPPORTED, "nn_conv3x3: image rows too wide for the staged range");
-    const size_t lds = lds_of(nw, mb);
+    const int nco = ck == 4 ? 64 : 32;
+    ConvShape sh;
+    if (!conv3x3_shape(W, Cin, sh))
+        return fail(FBSMI_ERR_UNSUPPORTED, "nn_conv3x3: image rows too wide for the staged range (ask fbsmi_nn_conv3x3_supported first)");
+    const int nw = sh.nw, mb = sh.mb;
+    const size_t lds = sh.lds;
     const int tile = 32 * mb * nw;
     const long long ntiles = (npix + tile - 1) / tile;
     const long long cap = 256 * (long long)((160 * 1024) / lds);   // workgroups resident at once

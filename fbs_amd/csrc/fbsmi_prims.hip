@@ -92,7 +92,7 @@ __global__ void k_math_map(int op, const float* x, const float* y, int64_t n, fl
 // tree kernels
 // ------------------------------------------------------------------------------------------
 // value of the quantity being reduced / scanned at element e
-enum { V_PLAIN = 0, V_EXPSHIFT = 1, V_JPROB = 2, V_FMREST = 3, V_FMALPHA = 4 };
+enum { V_PLAIN = 0, V_EXPSHIFT = 1, V_JPROB = 2, V_FMREST = 3, V_FMALPHA = 4, V_WSQ = 5 };
 
 struct ValArgs {
     const float* x;
@@ -100,6 +100,7 @@ struct ValArgs {
     // V_EXPSHIFT: exp(x - shift), shift = finite_or_zero(max of partmax)
     // V_JPROB:    (1 - x/wmax)/n with [iref] = jfix (jfix < 0 -> 0)
     // V_FMREST:   force_move rest weights ;  V_FMALPHA: nan->0 (temp*rest/(1-w))
+    // V_WSQ:      w * w with w = exp(x - *jfix) (jfix: device scalar holding the logsumexp): the terms of 1 / ESS
     const float* partmax;
     int nbmax;
     int32_t iref;
@@ -112,6 +113,10 @@ __device__ __forceinline__ float val_at(const ValArgs& a, int64_t e, float shift
     const float v = a.x[e];
     if (VAL == V_PLAIN) return v;
     if (VAL == V_EXPSHIFT) return fbsmi_expf(v - shift_or_wmax);
+    if (VAL == V_WSQ) {
+        const float w = fbsmi_expf(v - shift_or_wmax);
+        return w * w;
+    }
     if (VAL == V_JPROB) {
         if (e == a.iref) return a.jfix ? *a.jfix : 0.0f;
         return (1.0f - v / shift_or_wmax) / (float)a.n;
@@ -135,6 +140,7 @@ __device__ __forceinline__ float val_prologue(const ValArgs& a, float* s4) {
     if (VAL == V_EXPSHIFT) return finite_or_zero(top_max(a.partmax, a.nbmax, s4));
     if (VAL == V_JPROB) return top_max(a.partmax, a.nbmax, s4);
     if (VAL == V_FMREST || VAL == V_FMALPHA) return a.x[a.iref];
+    if (VAL == V_WSQ) return *a.jfix;
     return 0.0f;
 }
 
@@ -247,13 +253,14 @@ __global__ void __launch_bounds__(kBlock) k_lse_final(const float* partmax, TopR
 }
 
 // 1 workgroup: out[0] = root of partials, optionally transformed: mode 1 -> max(1 - root, 0),
-// mode 2 -> clip(root, 0, 1)
+// mode 2 -> clip(root, 0, 1), mode 3 -> 1 / root
 __global__ void __launch_bounds__(kBlock) k_root_final(TopRef top, int mode, float* out) {
     __shared__ float s_top[256];
     float root, P, E;
     top_get(top, 0, s_top, root, P, E);
     if (mode == 1) root = fmaxf(1.0f - root, 0.0f);
     if (mode == 2) root = root < 0.0f ? 0.0f : (root > 1.0f ? 1.0f : root);
+    if (mode == 3) root = 1.0f / root;
     if (threadIdx.x == 0) out[0] = root;
 }
 
@@ -671,6 +678,24 @@ int fbsmi_normalise(const float* lw, int64_t n, int log_space, float* out, float
     float* lse = out_lse ? out_lse : W.scal;
     int rc = logsumexp_impl(lw, n, lse, W, (hipStream_t)stream);
     if (rc) return rc;
+    k_normalise<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(lw, n, lse, log_space, out);
+    FBSMI_LAUNCH_CHECK();
+    return FBSMI_OK;
+}
+
+int fbsmi_normalise_ess(const float* lw, int64_t n, int log_space, float* out, float* out_lse, float* out_ess, void* ws,
+                        void* stream) {
+    FBSMI_NEED(n >= 1 && lw && out && ws, "normalise_ess: bad arguments");
+    Workspace W = carve(ws, n);
+    float* lse = out_lse ? out_lse : W.scal;
+    int rc = logsumexp_impl(lw, n, lse, W, (hipStream_t)stream);
+    if (rc) return rc;
+    if (out_ess) {   // before `out` is written: out may alias lw
+        ValArgs a = plain(lw, n);
+        a.jfix = lse;
+        rc = root_val<V_WSQ>(a, 3, out_ess, W, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     k_normalise<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(lw, n, lse, log_space, out);
     FBSMI_LAUNCH_CHECK();
     return FBSMI_OK;

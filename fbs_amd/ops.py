@@ -199,11 +199,17 @@ def logsumexp(x: torch.Tensor) -> torch.Tensor:
     return out.reshape(())
 
 
-def normalise(log_weights: torch.Tensor, log_space: bool = False, return_lse: bool = False):
-    """fbs/samplers/csmc/csmc.py:273-292."""
+def normalise(log_weights: torch.Tensor, log_space: bool = False, return_lse: bool = False, return_ess: bool = False):
+    """fbs/samplers/csmc/csmc.py:273-292.  return_lse / return_ess add the logsumexp (the step's increment of the log
+    normalising constant) and the effective sample size 1 / sum w^2 as 0-d device tensors (no host synchronisation)."""
     lw = _f32c(log_weights, "log_weights").reshape(-1)
     out = torch.empty_like(lw)
     lse = torch.empty(1, dtype=torch.float32, device=lw.device)
+    if return_ess:
+        ess = torch.empty(1, dtype=torch.float32, device=lw.device)
+        _lib.call("fbsmi_normalise_ess", lw.data_ptr(), lw.numel(), int(bool(log_space)), out.data_ptr(), lse.data_ptr(),
+                  ess.data_ptr(), _ws(lw.numel(), lw.device).data_ptr(), _stream())
+        return (out, lse.reshape(()), ess.reshape(())) if return_lse else (out, ess.reshape(()))
     _lib.call("fbsmi_normalise", lw.data_ptr(), lw.numel(), int(bool(log_space)), out.data_ptr(), lse.data_ptr(),
               _ws(lw.numel(), lw.device).data_ptr(), _stream())
     return (out, lse.reshape(())) if return_lse else out

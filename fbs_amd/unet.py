@@ -176,7 +176,14 @@ def _conv3x3_fusable(x, weight, stride=(1, 1), padding=(1, 1)) -> bool:
     # 64 channels wide or the rows are short enough for the 8- or 6-wave tile (1.1-2.4x); wider rows x wide outputs stay
     # with MIOpen
     wide = any(t.shape[1] >= 128 for t in parts)
-    return (not wide) or weight.shape[0] == 64 or x0.shape[3] <= 32
+    if wide and not (weight.shape[0] == 64 or x0.shape[3] <= 32):
+        return False
+    # ... and only where the kernel has a tile shape for rows this wide (its staged pixel range must fit LDS: W < 248 for
+    # 64-channel slices, W <= 100 for 128-channel ones); wider images keep the library convolution
+    from . import _lib
+    H, W = int(x0.shape[2]), int(x0.shape[3])
+    widths = {width for t in parts for _, width in _channel_chunks(t.shape[1])}
+    return all(_lib.lib().fbsmi_nn_conv3x3_supported(H, W, width, int(weight.shape[0])) == 1 for width in widths)
 
 
 def _conv3x3_hip(x, w16, bias):

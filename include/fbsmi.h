@@ -68,6 +68,12 @@ int fbsmi_logsumexp(const float* x, int64_t n, float* out, void* ws, void* strea
 /* fbs/samplers/csmc/csmc.py:273-292 normalise: out = lw - logsumexp(lw) (exp'd unless log_space);
  * out may alias lw; out_lse (nullable) receives the logsumexp. */
 int fbsmi_normalise(const float* lw, int64_t n, int log_space, float* out, float* out_lse, void* ws, void* stream);
+/* The same with the two diagnostics a sharded / monitored run reports per step (SURVEY.md 8b `out_ess`; the reference
+ * computes neither): out_lse (nullable) = logsumexp(lw), the increment of the log normalising constant when lw are the
+ * unnormalised log-weights of a step (csmc.py:146, smc.py:145-146 `c`); out_ess (nullable) = 1 / sum_i w_i^2 with
+ * w_i = exp(lw_i - lse) in float32, the sum being the root of the pairwise tree over the index bits. */
+int fbsmi_normalise_ess(const float* lw, int64_t n, int log_space, float* out, float* out_lse, float* out_ess, void* ws,
+                        void* stream);
 /* jnp.searchsorted(a, q, side='left') for m queries */
 int fbsmi_searchsorted(const float* a, int32_t n, const float* q, int64_t m, int32_t* out, void* stream);
 

@@ -37,6 +37,11 @@ int fbsmi_nn_qkv_linear_attention(const void* xn, const void* w, void* out, int6
 int fbsmi_nn_conv3x3(const void* x, int32_t xstride, const void* w, int32_t wstride, int32_t ci_off, const float* bias, void* y,
                      int accumulate, int64_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
 
+/* 1 when fbsmi_nn_conv3x3 has a tile shape for rows of W pixels and slices of Cin channels (the staged pixel range must fit
+ * 160 KB of LDS beside the weights: W < 248 at Cin = 64, W <= 100 at Cin = 128), else 0: the caller then keeps the library
+ * convolution.  No GPU work. */
+int fbsmi_nn_conv3x3_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+
 /* 1x1 projection to 64 channels, bfloat16 on the matrix cores, with its consumer folded in:
  *   y = [LN_c]( a Wa^T [+ b Wb^T] [+ bias] ) [* ln_scale] [+ residual]
  * a (npix, Ca), b (npix, Cb) or NULL: token-major inputs whose concatenation w (64, Ca + Cb) multiplies ((Ca, Cb) in

@@ -99,6 +99,8 @@ def _declare(L):
     L.orc_logsumexp.argtypes = [_f32p, C.c_int64]
     L.orc_logsumexp.restype = C.c_float
     L.orc_normalise.argtypes = [_f32p, C.c_int64, C.c_int]
+    L.orc_ess.argtypes = [_f32p, C.c_int64]
+    L.orc_ess.restype = C.c_float
     for name in ("orc_exp", "orc_log", "orc_erfinv", "orc_log1p", "orc_sqrt"):
         getattr(L, name).argtypes = [_f32p, C.c_int64, _f32p]
     L.orc_div.argtypes = [_f32p, _f32p, C.c_int64, _f32p]
@@ -231,6 +233,12 @@ def normalise(lw, log_space: bool = False) -> np.ndarray:
     out = _f32(lw).copy()
     lib().orc_normalise(out, out.size, int(log_space))
     return out
+
+
+def ess(lw) -> np.float32:
+    """1 / sum w^2 of the normalised weights (orc_ess): a diagnostic of this build, not of the reference."""
+    x = _f32(lw)
+    return np.float32(lib().orc_ess(x, x.size))
 
 
 def _map1(name, x):

@@ -265,6 +265,21 @@ ORC_API void orc_normalise(float* lw, int64_t n, int log_space) {
     }
 }
 
+/* Effective sample size of the unnormalised log-weights lw: 1 / sum_i w_i^2, w_i = exp(lw_i - logsumexp(lw)) in float32,
+ * the sum in the canonical pairwise-tree order.  A diagnostic of this build (SURVEY.md 8b `out_ess`): the reference
+ * computes no ESS; the definition follows its normalise (csmc.py:289-292) for the weights. */
+ORC_API float orc_ess(const float* lw, int64_t n) {
+    const float c = orc_logsumexp(lw, n);
+    float* q = (float*)malloc(sizeof(float) * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const float w = fbsmi_expf(lw[i] - c);
+        q[i] = w * w;
+    }
+    const float s = orc_sum(q, n);
+    free(q);
+    return 1.0f / s;
+}
+
 ORC_API void orc_exp(const float* x, int64_t n, float* out) {
     ORC_PARALLEL_FOR
     for (int64_t i = 0; i < n; ++i) out[i] = fbsmi_expf(x[i]);

@@ -79,6 +79,11 @@ def test_cumsum_sum_logsumexp_bit_exact(n, oracle, dev):
     for log_space in (True, False):
         got = _np(ops.normalise(lwt, log_space=log_space))
         np.testing.assert_array_equal(got.view(np.uint32), oracle.normalise(lw, log_space).view(np.uint32))
+    # fbsmi_normalise_ess: the same normalisation plus the step's log-normaliser increment and the ESS
+    out, lse, ess = ops.normalise(lwt, log_space=True, return_lse=True, return_ess=True)
+    np.testing.assert_array_equal(_np(out).view(np.uint32), oracle.normalise(lw, True).view(np.uint32))
+    assert np.float32(_np(lse)).view(np.uint32) == np.float32(oracle.logsumexp(lw)).view(np.uint32)
+    assert np.float32(_np(ess)).view(np.uint32) == np.float32(oracle.ess(lw)).view(np.uint32)
 
 
 def test_searchsorted_bit_exact(oracle, dev):

@@ -273,3 +273,18 @@ def test_openmp_build_is_bit_identical(oracle):
     b, used = oracle.bench_gibbs_lg(m, 7, [0.0], toy["y0"], 8192, 1, threads=4)
     assert used >= 1
     assert a.view(np.uint32) == b.view(np.uint32)
+
+
+def test_ess_definition_against_float64():
+    """orc_ess = 1 / sum w^2 of the normalised weights: against float64 numpy, and its two closed forms (uniform weights:
+    n; one dominant weight: 1)."""
+    import oracle as O
+    rng = np.random.default_rng(7)
+    for n in (1, 5, 1000, 70001):
+        lw = rng.normal(0, 1.5, n).astype(np.float32)
+        w = np.exp(lw.astype(np.float64) - np.logaddexp.reduce(lw.astype(np.float64)))
+        assert abs(float(O.ess(lw)) - 1.0 / np.sum(w * w)) <= 2e-5 / np.sum(w * w)
+        assert abs(float(O.ess(np.full(n, -3.0, np.float32))) - n) <= 1e-5 * n
+    lw = np.full(100, -80.0, np.float32)
+    lw[17] = 0.0
+    assert float(O.ess(lw)) == 1.0

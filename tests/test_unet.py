@@ -248,6 +248,55 @@ def test_conv3x3_over_channel_slices_and_unconcatenated_inputs(B, H, W, parts, c
     assert got.shape == want.shape and bool(((got - want).abs() <= tol).all()), (got - want).abs().max().item()
 
 
+def test_conv3x3_supported_query_matches_the_kernel_limits():
+    """fbsmi_nn_conv3x3_supported (host-only: no GPU work) is what unet.py asks before routing a convolution to the kernel;
+    its bound is the LDS footprint of the staged pixel range: W < 248 at 64-channel slices, W <= 100 at 128-channel ones
+    (celeba-128 / celeba-256 rows are configurable in the reference: those must fall back, not raise)."""
+    from fbs_amd import _lib
+    q = _lib.lib().fbsmi_nn_conv3x3_supported
+    assert q(28, 28, 64, 64) == 1 and q(64, 64, 128, 64) == 1 and q(128, 128, 64, 64) == 1
+    assert q(128, 128, 128, 64) == 0 and q(256, 256, 64, 64) == 0 and q(256, 256, 128, 128) == 0
+    assert q(8, 100, 128, 64) == 1 and q(8, 101, 128, 64) == 0
+    assert q(8, 247, 64, 64) == 1 and q(8, 248, 64, 64) == 0
+    assert q(8, 8, 32, 64) == 0 and q(8, 8, 64, 32) == 0 and q(0, 8, 64, 64) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,cin,cout", [(8, 128, 64, 64), (8, 128, 128, 64), (4, 256, 64, 64), (4, 256, 128, 128)])
+def test_wide_rows_fall_back_to_the_library_convolution(H, W, cin, cout):
+    """Rows too wide for the kernel's staged range (ADVICE r2): the dispatch must take the library path instead of raising;
+    where the kernel does have a tile shape (W = 128 at 64 channels) it is used and must agree."""
+    from fbs_amd.unet import WeightStandardizedConv, _conv3x3_fusable
+    dev = torch.device("cuda:0")
+    torch.manual_seed(W + cin)
+    m = WeightStandardizedConv(cin, cout).to(dev).eval()
+    x = torch.randn(2, cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.enable_grad():
+        want = m(x).detach()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        x16 = x.to(torch.bfloat16)
+        fus = _conv3x3_fusable(x16, m._standardised().to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+        got = m(x16).float()
+    assert fus == (W == 128 and cin == 64)
+    assert (got - want).abs().max().item() <= 4e-2 * max(want.abs().max().item(), 1.0)
+
+
+@pytest.mark.gpu
+def test_conv3x3_many_slices_rounding_is_bounded():
+    """A 256 + 256 channel up-path convolution is four slice launches, the partial sum rounded to bfloat16 between them
+    (ADVICE r2): the error against one float32 accumulation stays within (slices - 1) roundings of the result's scale."""
+    from fbs_amd.unet import _conv3x3_hip
+    dev = torch.device("cuda:0")
+    torch.manual_seed(512)
+    xs = tuple(torch.randn(2, 256, 14, 14, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(2))
+    w = (torch.randn(128, 512, 3, 3, device=dev) / (3 * 512 ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        got = _conv3x3_hip(xs, w, None).float()
+    want = torch.nn.functional.conv2d(torch.cat([t.float() for t in xs], dim=1), w.float(), None, padding=1)
+    tol = 2.0 ** -8 * want.abs() + 3 * 2.0 ** -9 * 2.0 * want.abs().max() + 4e-3
+    assert bool(((got - want).abs() <= tol).all()), (got - want).abs().max().item()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,chans,ln", [(3, 28, 28, (128,), True), (2, 9, 7, (64, 64), False), (5, 5, 5, (64,), False),
                                            (1, 64, 64, (128,), True), (2, 14, 14, (64, 64), True)])
