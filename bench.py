@@ -99,53 +99,60 @@ def gp100_leg(dev):
                     "and latency-bound"}
 
 
-def image_legs(dev, nsteps):
-    """Configs 3-5 in shape (fbs_amd/image_configs.py: synthetic image, random-init UNet dim 64, bf16): one
-    gibbs_kernel sweep of `nsteps` of the configuration's steps on this GPU's share of the particles, network time
-    (torch events around every network call) and sampler time (everything else) apart.  `ms_per_step` = the timed sweep
-    divided by its steps (it carries the sweep's fixed parts: with 6 steps, explicit_final's initial weights alone are a
-    seventh network evaluation); `ms_per_step_marginal` = what one more step costs."""
+def image_legs(dev, nsteps, dtypes=("f32", "bf16")):
+    """Configs 3-5 in shape (fbs_amd/image_configs.py: synthetic image, random-init UNet dim 64): one gibbs_kernel sweep of
+    `nsteps` of the configuration's steps on this GPU's share of the particles, network time (torch events around every
+    network call) and sampler time (everything else) apart.  Two arithmetic types: **float32** is the configuration's number --
+    the reference's UNet computes in float32 (fbs/nn/unet.py:85-86, x64 off) -- and bf16 autocast (network input written,
+    output read in bfloat16 by the step kernels) is this build's fast path, reported beside it under `<label>` / `<label>_f32`.
+    `ms_per_step` = the timed sweep divided by its steps (it carries the sweep's fixed parts: with 6 steps, explicit_final's
+    initial weights alone are a seventh network evaluation); `ms_per_step_marginal` = what one more step costs (bf16 legs)."""
     from fbs_amd import image_configs, ops
     out = {}
-    for name, label in (("c3", "c3"), ("c4", "c4_shard"), ("c5", "c5_shard")):
-        c = image_configs.make(name, dev, dtype="bf16", nsteps=nsteps)
-        n = c.shard_rows
-        image_configs.gibbs_sweep(c, ops.PRNGKey(3), n)
-        torch.cuda.synchronize(dev)
-        image_configs.network_ms(c)
-        c.sb.profile = {}
-        t0 = time.perf_counter()
-        image_configs.gibbs_sweep(c, ops.PRNGKey(4), n)
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-        net_ms = image_configs.network_ms(c)
-        pr = c.sb.profile
-        ev = lambda a, b: sum(x.elapsed_time(y) for x, y in zip(pr[a], pr[b])) / max(1, len(pr[a])) * 1e3
-        full = image_configs.CONFIGS[name]
-        # a sweep has fixed parts (explicit_final's initial weights are one more network evaluation, the forward path, the
-        # final move): the MARGINAL step is the difference between two sweeps of different length
-        marginal = None
-        if nsteps >= 4:
-            ns2 = max(1, nsteps // 3)
-            c2 = image_configs.make(name, dev, dtype="bf16", nsteps=ns2)
-            image_configs.gibbs_sweep(c2, ops.PRNGKey(3), n)
+    for dtype in dtypes:
+        ns = nsteps if dtype == "bf16" else max(1, min(nsteps, 3))    # the float32 sweeps are ~4x as long: fewer steps
+        for name, label in (("c3", "c3"), ("c4", "c4_shard"), ("c5", "c5_shard")):
+            c = image_configs.make(name, dev, dtype=dtype, nsteps=ns)
+            n = c.shard_rows
+            image_configs.gibbs_sweep(c, ops.PRNGKey(3), n)
             torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            image_configs.gibbs_sweep(c2, ops.PRNGKey(4), n)
+            image_configs.network_ms(c)
+            c.sb.profile = {}
+            t0 = time.perf_counter()
+            image_configs.gibbs_sweep(c, ops.PRNGKey(4), n)
             torch.cuda.synchronize(dev)
-            marginal = (dt - (time.perf_counter() - t1)) / (nsteps - ns2) * 1e3
-            del c2
-        out[label] = {"workload": f"{full['task']} on {full['image']}, UNet dim 64 random init bf16, {n} particles on this GPU "
-                                  f"(+1: explicit_final; ensemble {full['nparticles']} over {full['ngpus']} GPU(s)), "
-                                  f"{nsteps} of the configuration's {full['nsteps']} steps timed",
-                      "ms_per_step": dt / nsteps * 1e3, "network_ms_per_step": net_ms / nsteps,
-                      "sampler_ms_per_step": (dt * 1e3 - net_ms) / nsteps, "particle_steps_per_s": n * nsteps / dt,
-                      "ms_per_step_marginal": marginal,
-                      "full_sweep_s_extrapolated": (dt + (marginal if marginal else dt / nsteps * 1e3) * 1e-3 * (full["nsteps"] - nsteps)),
-                      "concat_kernel_us_with_event_overhead": ev("concat0", "concat1"),
-                      "finish_kernel_us_with_event_overhead": ev("finish0", "finish1")}
-        del c
-        torch.cuda.empty_cache()
+            dt = time.perf_counter() - t0
+            net_ms = image_configs.network_ms(c)
+            pr = c.sb.profile
+            ev = lambda a, b: sum(x.elapsed_time(y) for x, y in zip(pr[a], pr[b])) / max(1, len(pr[a])) * 1e3
+            full = image_configs.CONFIGS[name]
+            # a sweep has fixed parts (explicit_final's initial weights are one more network evaluation, the forward path, the
+            # final move): the MARGINAL step is the difference between two sweeps of different length
+            marginal = None
+            if ns >= 4 and dtype == "bf16":
+                ns2 = max(1, ns // 3)
+                c2 = image_configs.make(name, dev, dtype=dtype, nsteps=ns2)
+                image_configs.gibbs_sweep(c2, ops.PRNGKey(3), n)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                image_configs.gibbs_sweep(c2, ops.PRNGKey(4), n)
+                torch.cuda.synchronize(dev)
+                marginal = (dt - (time.perf_counter() - t1)) / (ns - ns2) * 1e3
+                del c2
+            out[label + ("_f32" if dtype == "f32" else "")] = {
+                "workload": f"{full['task']} on {full['image']}, UNet dim 64 random init, {n} particles on this GPU "
+                            f"(+1: explicit_final; ensemble {full['nparticles']} over {full['ngpus']} GPU(s)), "
+                            f"{ns} of the configuration's {full['nsteps']} steps timed",
+                "dtype": "f32 (the reference's precision: this is the configuration's figure)" if dtype == "f32"
+                         else "bf16 autocast (fast path; narrower than the reference's float32 network)",
+                "ms_per_step": dt / ns * 1e3, "network_ms_per_step": net_ms / ns,
+                "sampler_ms_per_step": (dt * 1e3 - net_ms) / ns, "particle_steps_per_s": n * ns / dt,
+                "ms_per_step_marginal": marginal,
+                "full_sweep_s_extrapolated": (dt + (marginal if marginal else dt / ns * 1e3) * 1e-3 * (full["nsteps"] - ns)),
+                "concat_kernel_us_with_event_overhead": ev("concat0", "concat1"),
+                "finish_kernel_us_with_event_overhead": ev("finish0", "finish1")}
+            del c
+            torch.cuda.empty_cache()
     return out
 
 
@@ -245,6 +252,57 @@ def sharded_leg(dev, dist, world, rank, nsteps):
     return res
 
 
+def sharded_lg_leg(dev, dist, world, rank, nsteps):
+    """north_star's split on the Gaussian-bridge workload: ONE ensemble sharded over the ranks (fbs_amd/sharded.py: contiguous
+    slot ranges per rank, the log-weights all_gathered, the ancestor rows by all_gather -- rows of 4 / 400 bytes --, the
+    propagation and weighting on the local rows through the fbsmi_lg_*_rows kernels, the noise a row slice of the global
+    draw).  Two ensembles: BASELINE config 2's model at N = 2^22 (du = 1) and the reference's d = 100 toy at N = 131 072.
+    Strong scaling; `nsteps` SMC steps per timed sweep.  Also returns the per-step ESS / log-normaliser diagnostics."""
+    import fbs_amd
+    from fbs_amd import ops, sharded
+    from fbs_amd.sdes import StationaryConstLinearSDE
+    out = {}
+    d = 100
+    zs = np.linspace(0., 5., d)
+    cov = np.exp(-np.abs(zs[None, :] - zs[:, None]))
+    cases = {"toy2d_N4194304": (np.array([-1.0, 1.0]), np.array([[2.0, 0.4], [0.4, 0.5]]), 1, 1 << 22, T_END),
+             "gp100_N131072": (np.zeros(2 * d), np.block([[cov, cov], [cov, cov + np.eye(d)]]), d, 131072, 1.0)}
+    for name, (m0, cov0, du, N, tend) in cases.items():
+        ts = np.linspace(0.0, tend, nsteps + 1)
+        br = fbs_amd.LinearGaussianBridge(m0, cov0, StationaryConstLinearSDE(a=-0.5, b=1.0), ts, du=du, device=dev)
+        y0 = torch.zeros(br.dv, device=dev)
+        x0 = torch.zeros(du, device=dev)
+        bs = np.zeros(nsteps + 1, np.int32)
+        sh = sharded.ParticleShards(N, dist=dist, exchange="auto")
+        run = lambda key: sharded.gibbs_kernel(key, x0, y0, None, bs, ts, br.fwd_sampler, br.sde, br.unpack, N,
+                                               br.transition_sampler, br.transition_logpdf, br.likelihood_logpdf, sh)
+        run(ops.PRNGKey(7))
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        sh.bytes_moved = 0
+        t0 = time.perf_counter()
+        res = run(ops.PRNGKey(8))
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
+        diag = sh.diagnostics.cpu().numpy()
+        out[name] = {"value": float(N) * nsteps / dt, "unit": "particle-steps/s", "ms_per_step": dt / nsteps * 1e3,
+                     "nparticles": N, "du": du, "rows_per_rank": sh.n, "exchange": sh.exchange_for(torch.empty(1, du)),
+                     "ancestor_exchange_bytes_received_per_step_rank0": sh.bytes_moved / nsteps,
+                     "logweight_all_gather_bytes_per_step": 4 * (sh.world - 1) * sh.n,
+                     "ess_last_step": float(diag[-1, 1]), "log_normaliser_sum": float(diag[:, 0].sum()),
+                     "x0_checksum": float(res[0].double().sum().item())}
+        del br
+        torch.cuda.empty_cache()
+    out["workload"] = (f"one linear-Gaussian ensemble over {world} rank(s), closure tier + fbs_amd/sharded.py, gibbs_kernel eb=True "
+                       f"ef=False, {nsteps} SMC steps timed; strong scaling (host loop: ~15 launches and two collectives per step)")
+    out["scaling"] = "strong"
+    out["n_gpus"] = world
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,7 +318,12 @@ def main():
     ap.add_argument("--batch-scan", type=str, default="16,32",
                     help="extra chain-batch sizes timed (untimed region) and reported in `batch_scan`; '' to skip")
     ap.add_argument("--image-steps", type=int, default=6, help="SMC steps timed per image configuration (0: skip the legs)")
-    ap.add_argument("--sharded-steps", type=int, default=2, help="SMC steps of the sharded config-5 ensemble (0: skip)")
+    ap.add_argument("--image-dtype", choices=["both", "f32", "bf16"], default="both",
+                    help="arithmetic of the image legs' network: f32 = the reference's (the configurations' figures), bf16 = "
+                         "autocast fast path; both by default")
+    ap.add_argument("--sharded-steps", type=int, default=10, help="SMC steps of the sharded config-5 ensemble (0: skip)")
+    ap.add_argument("--sharded-lg-steps", type=int, default=20,
+                    help="SMC steps of the sharded linear-Gaussian ensembles (`sharded_lg`; 0: skip)")
     ap.add_argument("--no-spill", action="store_true", help="skip the beyond-the-Infinity-Cache leg (`spill`)")
     args = ap.parse_args()
 
@@ -456,7 +519,7 @@ def main():
         images, emroof = None, None
         if world == 1 and args.image_steps > 0 and not args.no_single_chain:
             emroof = em_finish_roofline(dev)
-            images = image_legs(dev, args.image_steps)
+            images = image_legs(dev, args.image_steps, ("f32", "bf16") if args.image_dtype == "both" else (args.image_dtype,))
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             import oracle as O
@@ -500,8 +563,15 @@ def main():
             shard = sharded_leg(dev, dist, world, rank, args.sharded_steps)
         except Exception as e:  # every rank runs the same deterministic code: a failure is reported, the headline stays
             shard = {"error": f"{type(e).__name__}: {e}"}
+    shard_lg = None
+    if args.sharded_lg_steps > 0 and not args.no_single_chain:
+        try:
+            shard_lg = sharded_lg_leg(dev, dist, world, rank, args.sharded_lg_steps)
+        except Exception as e:
+            shard_lg = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         out["sharded_c5"] = shard
+        out["sharded_lg"] = shard_lg
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

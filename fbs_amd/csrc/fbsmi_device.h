@@ -761,6 +761,48 @@ __device__ __forceinline__ void bisect_round3_x2(const float* __restrict__ a, in
     }
 }
 
+// K independent searches taking a three-level round together: all 7 K probes are issued before the first is used
+// (`on[k]` = false: no loads for search k, its interval untouched)
+template <int K>
+__device__ __forceinline__ void bisect_round3_xn(const float* __restrict__ a, int (&lo)[K], int (&hi)[K], const float (&q)[K],
+                                                 const bool (&on)[K]) {
+    int m1[K], m2l[K], m2r[K], m3a[K], m3b[K], m3c[K], m3d[K];
+    float v1[K], v2l[K], v2r[K], v3a[K], v3b[K], v3c[K], v3d[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int l0 = lo[k], h0 = hi[k];
+        m1[k] = (l0 + h0) >> 1;
+        m2l[k] = (l0 + m1[k]) >> 1;
+        m2r[k] = (m1[k] + h0) >> 1;
+        m3a[k] = (l0 + m2l[k]) >> 1;
+        m3b[k] = (m2l[k] + m1[k]) >> 1;
+        m3c[k] = (m1[k] + m2r[k]) >> 1;
+        m3d[k] = (m2r[k] + h0) >> 1;
+        // no load sits under a divergent branch (the compiler would drain the whole memory queue where the paths meet):
+        // searches that are off read element 0 -- one broadcast line -- and ignore it
+        const bool o = on[k];
+        v1[k] = a[o ? m1[k] : 0]; v2l[k] = a[o ? m2l[k] : 0]; v2r[k] = a[o ? m2r[k] : 0];
+        v3a[k] = a[o ? m3a[k] : 0]; v3b[k] = a[o ? m3b[k] : 0]; v3c[k] = a[o ? m3c[k] : 0]; v3d[k] = a[o ? m3d[k] : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int l = lo[k], h = hi[k];
+        const bool g1 = q[k] <= v1[k];
+        h = g1 ? m1[k] : h;
+        l = g1 ? l : m1[k];
+        const int m2 = g1 ? m2l[k] : m2r[k];
+        const bool g2 = q[k] <= (g1 ? v2l[k] : v2r[k]);
+        h = g2 ? m2 : h;
+        l = g2 ? l : m2;
+        const int m3 = g1 ? (g2 ? m3a[k] : m3b[k]) : (g2 ? m3c[k] : m3d[k]);
+        const bool g3 = q[k] <= (g1 ? (g2 ? v3a[k] : v3b[k]) : (g2 ? v3c[k] : v3d[k]));
+        h = g3 ? m3 : h;
+        l = g3 ? l : m3;
+        lo[k] = on[k] ? l : lo[k];
+        hi[k] = on[k] ? h : hi[k];
+    }
+}
+
 // Three levels in one memory round trip (`on` = false: no loads, interval untouched)
 __device__ __forceinline__ void bisect_round3(const float* __restrict__ a, int& lo, int& hi, float q, bool on) {
     if (!on) return;

@@ -426,6 +426,43 @@ __global__ void __launch_bounds__(kBlock) k_lg_init(LgDev dd) {
 // per-workgroup partials of the previous kernel are re-reduced through a tile-shaped top tree
 // (top_load / top_leaf) and searches use bisect_heap.
 // ------------------------------------------------------------------------------------------
+// A thread's chunk of ITEMS consecutive elements (the leaves of its subtree in the canonical summation tree) as 16-byte
+// accesses when the whole chunk exists: one guarded dword per element -- what the straightforward loop compiles to, the
+// guard forbids merging -- makes every wave instruction touch 64 separate cache lines, and the several-slots-per-thread
+// kernels (N > 131072) then run at a tenth of the memory rate (measured: k_lg_norm<16> 0.7 TB/s).  Per-chain arrays are
+// only 4-byte aligned (N is arbitrary), hence the vector type's alignment.
+typedef float lg_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int ITEMS>
+__device__ __forceinline__ void chunk_load(const float* __restrict__ p, int base, int n, float fill, float (&x)[ITEMS]) {
+    if (ITEMS % 4 == 0 && base + ITEMS <= n) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i += 4) {
+            const lg_f4u q = *reinterpret_cast<const lg_f4u*>(p + base + i);
+            x[i] = q.x; x[i + 1] = q.y; x[i + 2] = q.z; x[i + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) x[i] = base + i < n ? p[base + i] : fill;
+    }
+}
+
+template <int ITEMS>
+__device__ __forceinline__ void chunk_store(float* __restrict__ p, int base, int n, const float (&x)[ITEMS]) {
+    if (ITEMS % 4 == 0 && base + ITEMS <= n) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i += 4) {
+            lg_f4u q;
+            q.x = x[i]; q.y = x[i + 1]; q.z = x[i + 2]; q.w = x[i + 3];
+            *reinterpret_cast<lg_f4u*>(p + base + i) = q;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (base + i < n) p[base + i] = x[i];
+    }
+}
+
 __device__ __forceinline__ float block_max4(float m, float* lds4) {  // lds4 untouched since the last barrier
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = m;
@@ -483,8 +520,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
     const int base = (bx * kBlock + threadIdx.x) * ITEMS;
     const int i_ref = d.bs[MODE == 0 ? s : d.T];
     float l[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) l[i] = base + i < d.N ? d.lw[base + i] : 0.0f;
+    chunk_load<ITEMS>(d.lw, base, d.N, 0.0f, l);
     const float l_ref = MODE == 1 ? d.lw[i_ref] : 0.0f;
     // two-level logsumexp: combine the per-workgroup (max, sumexp) pairs the previous kernel published
     float lse, Mraw;
@@ -492,24 +528,25 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
     if (MODE == 0) { FBSMI_STAMP(14) }
     const float w_max = fbsmi_expf(Mraw - lse);  // == max_i w_i: fbsmi_expf is monotone
     const float w_k = MODE == 1 ? fbsmi_expf(l_ref - lse) : 0.0f;
-    float xw[ITEMS], xj[ITEMS];
+    float xw[ITEMS], xj[ITEMS], ln[ITEMS];
     const float inv_n = 1.0f / (float)d.N;   // PUB: N is a power of two, x / N == x * (1 / N) exactly
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int e = base + i;
         xw[i] = 0.0f;
         xj[i] = 0.0f;
+        ln[i] = 0.0f;
         if (e < d.N) {
-            const float ln = l[i] - lse;
-            const float w = fbsmi_expf(ln);
-            d.w[e] = w;
-            if (MODE != 0) d.lwn[e] = ln;   // read back only after the final normalisation (view 1)
-            if (d.lwss) d.lwss[(size_t)s * d.N + e] = ln;
+            ln[i] = l[i] - lse;
+            const float w = fbsmi_expf(ln[i]);
             xw[i] = w;
             if (MODE == 0) xj[i] = e == i_ref ? 0.0f : (PUB ? jprob_pow2(w, w_max, inv_n) : jprob_at(w, w_max, d.N));
             if (MODE == 1) xj[i] = fm_rest_at(w, w_k, e == i_ref, d.N);
         }
     }
+    chunk_store<ITEMS>(d.w, base, d.N, xw);
+    if (MODE != 0) chunk_store<ITEMS>(d.lwn, base, d.N, ln);   // read back only after the final normalisation (view 1)
+    if (d.lwss) chunk_store<ITEMS>(d.lwss + (size_t)s * d.N, base, d.N, ln);
     float s2[2] = {chunk_total<ITEMS>(xw), chunk_total<ITEMS>(xj)}, t2[2];
     TreePath p2[2];
     block_upsweep_n<2>(s2, p2, xch[2], t2);
@@ -553,8 +590,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
     const float w_max = d.scal[1];
     const float w_k = d.scal[2];
     float wv[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) wv[i] = base + i < d.N ? d.w[base + i] : 0.0f;
+    chunk_load<ITEMS>(d.w, base, d.N, 0.0f, wv);
     if (MODE == 1) {
         float pj[kTopItems];
         top_load(d.bsumJ, d.nb, pj);
@@ -568,9 +604,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
         top_leaf(pj, p2[0], t2[0], b, bc[0], P, E);
         block_descend(P, E, p2[1]);
         chunk_scan<ITEMS>(x, P, E, c);
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i)
-            if (base + i < d.N) d.cdf[base + i] = c[i];
+        chunk_store<ITEMS>(d.cdf, base, d.N, c);
         return;
     }
     float pw[kTopItems];
@@ -584,9 +618,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
         top_leaf(pw, p2[0], t2[0], b, bc[0], P, E);
         block_descend(P, E, p2[1]);
         chunk_scan<ITEMS>(wv, P, E, c);
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i)
-            if (base + i < d.N) d.cdf[base + i] = c[i];
+        chunk_store<ITEMS>(d.cdf, base, d.N, c);
         return;
     }
     // ---- MODE 0
@@ -601,8 +633,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
     const int b_ref = i_ref / TILE;
     const int rbase = b_ref * TILE + threadIdx.x * ITEMS;
     float wr[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) wr[i] = rbase + i < d.N ? d.w[rbase + i] : 0.0f;
+    chunk_load<ITEMS>(d.w, rbase, d.N, 0.0f, wr);
     float pj[kTopItems];
     top_load(d.bsumJ, d.nb, pj);
     // phase 1: top(bsumw), top(bsumJ) [for the total], own w tile -- one exchange
@@ -656,17 +687,13 @@ __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
     float c[ITEMS];
     block_descend(P, E, p3[2]);
     chunk_scan<ITEMS>(wv, P, E, c);
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i)
-        if (base + i < d.N) d.cdf[base + i] = c[i];
+    chunk_store<ITEMS>(d.cdf, base, d.N, c);
     if (ITEMS == 1 && hp_node) d.hpW[hp_node] = c[0];
     P = bc[1][0];
     E = bc[1][1];
     block_descend(P, E, p2[1]);
     chunk_scan<ITEMS>(xo, P, E, c);
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i)
-        if (base + i < d.N) d.cdfJ[base + i] = c[i];
+    chunk_store<ITEMS>(d.cdfJ, base, d.N, c);
     if (ITEMS == 1 && hp_node && hp_depth < d.lh_j) d.hpJ[hp_node] = c[0];
     FBSMI_STAMP(5)
 }
@@ -890,6 +917,157 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop1(LgDev dd, int s) {
         d.bsumexp[blockIdx.x] = sx;
     }
     FBSMI_STAMP(13)
+}
+
+// ------------------------------------------------------------------------------------------
+// Several slots per thread (N > 131072: tiles of 1024 / 4096 slots, ITEMS = 4 / 16), the HBM-resident regime.
+// k_lg_prop above walks a thread's slots one after the other, each with its own chain of dependent probes (the search of
+// a killed slot alone is five global round trips behind eight LDS levels) and with the thread's ITEMS slots CONSECUTIVE
+// in memory -- a wave's load touches 64 cache lines.  Measured at 4 x 2^22 particles: 1.3 ms per step, 0.05 of the HBM
+// roof, the CUs waiting on ~160 serial round trips per thread.  Here:
+//   * slot i of thread t is element tile0 + i * 256 + t: every access of a wave is one contiguous run;
+//   * the slots are taken four at a time, all loads of a stage issued before the first is used, the four searches in
+//     lockstep (bisect_round3_xn): a batch costs the round trips of ONE slot;
+//   * the compact heaps of both CDFs (11 / 8 levels) come from k_lg_heaps, a launch of eight workgroups behind k_lg_cdf,
+//     so a workgroup stages them with two coalesced loads per thread and a search leaves LDS with 2048 candidates left;
+//   * the tile's (max, sumexp) wants the canonical chunk order (thread t owns elements t * ITEMS ..): the new log-weights
+//     cross LDS once.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_lg_heaps(LgDev dd) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    const int t = blockIdx.x * kBlock + threadIdx.x;   // node of the implicit bisection tree (root 1); grid.x = kHeapSizeW / kBlock
+    if (t < 1 || t >= kHeapSizeW) return;
+    const int depth = 31 - __builtin_clz(t);
+    if (depth >= d.lh_w) return;
+    const int mid = heap_node_mid(t, d.N);
+    d.hpW[t] = d.cdf[mid];
+    if (t < kHeapSizeJ && depth < d.lh_j) d.hpJ[t] = d.cdfJ[mid];
+}
+
+template <int ITEMS, int DMAX>
+__global__ void __launch_bounds__(kBlock) k_lg_propN(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    constexpr int B = ITEMS < 4 ? ITEMS : 4;       // slots in flight per thread
+    constexpr int TILE = kBlock * ITEMS;
+    __shared__ float xch[2][4];
+    __shared__ __attribute__((aligned(16))) float heapW[kHeapSizeW];
+    __shared__ float heapJ[kHeapSizeJ];
+    __shared__ float win[kBlock];
+    __shared__ __attribute__((aligned(16))) float lvs[TILE];
+    const int N = d.N;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], t0 = kt[6], t1 = kt[7];
+    const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
+    const int tile0 = blockIdx.x * TILE;
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    // ---- round 0
+    const float lastJ = d.cdfJ[N - 1];
+    const float last = d.cdf[N - 1];
+    const float w_max = d.scal[1];
+    static_assert(kHeapSizeW == 8 * kBlock && kHeapSizeJ == kBlock, "heap staging assumes 2048 / 256 nodes");
+    const float4 hw0 = reinterpret_cast<const float4*>(d.hpW)[2 * threadIdx.x];
+    const float4 hw1 = reinterpret_cast<const float4*>(d.hpW)[2 * threadIdx.x + 1];
+    const float hj = d.hpJ[threadIdx.x];
+    const StepTables<DMAX> t = step_tables<DMAX>(d, s);
+    const float* v_prev = d.vs + (size_t)s * d.dv;
+    const float* v = d.vs + (size_t)(s + 1) * d.dv;
+    const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
+    const float u3 = __uint_as_float(kt[4]);
+    reinterpret_cast<float4*>(heapW)[2 * threadIdx.x] = hw0;
+    reinterpret_cast<float4*>(heapW)[2 * threadIdx.x + 1] = hw1;
+    heapJ[threadIdx.x] = hj;
+    __syncthreads();
+    // ---- round 1: J = choice(key_3, N, (), p=J_prob) (resamplings.py:84); roll by j - J (:85)
+    const int J = bisect_uniform(d.cdfJ, N, d.levels, d.lh_j, heapJ, win, lastJ * (1.0f - u3));
+    int shift = (j_ref - J) % N;
+    if (shift < 0) shift += N;
+#pragma unroll 1
+    for (int i0 = 0; i0 < ITEMS; i0 += B) {
+        int m[B], src[B];
+        bool live[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            m[k] = tile0 + (i0 + k) * kBlock + (int)threadIdx.x;
+            live[k] = m[k] < N;
+            int sc = m[k] - shift;
+            if (sc < 0) sc += N;
+            src[k] = live[k] ? sc : 0;
+        }
+        // ---- round 2: the sources' weights, rotated but contiguous
+        float ws[B], u[B][DMAX];
+#pragma unroll
+        for (int k = 0; k < B; ++k) ws[k] = d.w[src[k]];
+        float qK[B], xi[B][DMAX];
+        bool killed[B];
+        int lo[B], hi[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const float u1 = uniform_at(a0, a1, (uint64_t)N, (uint64_t)src[k]);
+            const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)src[k]);
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r)
+                xi[k][r] = r < d.du ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)(live[k] ? m[k] : 0) * d.du + r) : 0.0f;
+            qK[k] = last * (1.0f - u2);                                      // resamplings.py:73-74
+            bisect_lds_levels(N, d.lh_w, heapW, qK[k], lo[k], hi[k]);
+            killed[k] = live[k] && (u1 * w_max >= ws[k]);                     // :71
+        }
+        // ---- rounds 3..: the killed slots' searches, in lockstep
+#pragma unroll 1
+        for (int rem = d.levels - d.lh_w; rem > 0; rem -= 3) bisect_round3_xn<B>(d.cdf, lo, hi, qK, killed);
+        // ---- the ancestors' rows (a survivor's is its own source: contiguous; no load under a divergent branch)
+        int a[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const bool pinned = m[k] == j_ref;
+            a[k] = pinned ? i_ref : (killed[k] ? hi[k] : src[k]);            // :86
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) u[k][r] = r < d.du ? up[(size_t)r * N + a[k]] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const bool pinned = m[k] == j_ref;
+            float l = -__builtin_inff();
+            if (live[k]) {
+                if (d.As) d.As[(size_t)s * N + m[k]] = a[k];
+                // transition_sampler (gp_gibbs.py:120-122) and the pin of csmc.py:143
+#pragma unroll
+                for (int r = 0; r < DMAX; ++r) {
+                    if (r < d.du) {
+                        const float dr = drift_row<DMAX>(t, r, u[k], v_prev);
+                        float x = (u[k][r] + dr * t.dt) + t.sd * xi[k][r];
+                        if (pinned) x = ustar[r];
+                        un[(size_t)r * N + m[k]] = x;
+                        if (d.uss) d.uss[((size_t)(s + 1) * N + m[k]) * d.du + r] = x;
+                    }
+                }
+                l = lg_loglik<DMAX>(t, u[k], v, v_prev);   // likelihood_logpdf on the gathered particle (csmc.py:145)
+                d.lw[m[k]] = l;
+            }
+            lvs[(i0 + k) * kBlock + threadIdx.x] = l;
+        }
+    }
+    __syncthreads();
+    float lv[ITEMS];
+    if (ITEMS % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i += 4) {
+            const float4 q4 = *reinterpret_cast<const float4*>(lvs + threadIdx.x * ITEMS + i);
+            lv[i] = q4.x; lv[i + 1] = q4.y; lv[i + 2] = q4.z; lv[i + 3] = q4.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) lv[i] = lvs[threadIdx.x * ITEMS + i];
+    }
+    float mx, sx;
+    block_lse_partial<ITEMS>(lv, xch[0], xch[1], mx, sx);
+    if (threadIdx.x == 0) {
+        d.bmax[blockIdx.x] = mx;
+        d.bsumexp[blockIdx.x] = sx;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3012,6 +3190,10 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
             } else if (s->items == 1 && !s->generic_prop) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1<DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
+            } else if (s->items > 1 && !s->generic_prop) {
+                // several slots per thread: compact heaps by their own small launch, then the batched kernel
+                k_lg_heaps<<<dim3(kHeapSizeW / kBlock, d.C), kBlock, 0, st>>>(d);
+                LG_DISPATCH(s, (k_lg_propN<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
             } else {
                 LG_DISPATCH(s, (k_lg_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
             }
@@ -3186,12 +3368,12 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     d.hp_map = nullptr;
     int32_t* hp_map_dev = nullptr;
     d.lh_w = d.lh_j = 0;
-    if (s->items == 1) {
+    if (!wide) {   // compact bisection heaps: written by k_lg_cdf itself (one slot per thread, through hp_map) or by k_lg_heaps
         int fl = 0;
         while ((2ll << fl) <= (long long)d.N) ++fl;   // floor(log2 N)
         d.lh_w = fl < kHeapLevelsW ? fl : kHeapLevelsW;
         d.lh_j = fl < kHeapLevelsJ ? fl : kHeapLevelsJ;
-        rc |= slab_request(s, &hp_map_dev, (size_t)N);
+        if (s->items == 1) rc |= slab_request(s, &hp_map_dev, (size_t)N);
         rc |= slab_request(s, &d.hpW, C * (size_t)kHeapSizeW);
         rc |= slab_request(s, &d.hpJ, C * (size_t)kHeapSizeJ);
     }

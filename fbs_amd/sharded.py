@@ -2,7 +2,8 @@
 
 The R rows of the ensemble (R = nparticles, or nparticles + 1 with explicit_final: gibbs.py:133-134) are cut
 into `world` contiguous shards of n = ceil(R / world) slots; rank g owns rows [g n, min((g + 1) n, R)) -- only
-the last shard can be short, its missing slots are padding that no weight, ancestor or draw ever refers to.
+the last shard can be short (a split that would leave a rank without rows is refused), its missing slots are padding
+that no weight, ancestor or draw ever refers to.
 What is expensive -- propagating and weighting particles through the model closures (the score network for
 images) -- runs on the local rows only.  Per SMC step there are exactly two exchanges:
 
@@ -18,9 +19,16 @@ images) -- runs on the local rows only.  Per SMC step there are exactly two exch
      ancestors are (config 5: 25 MB per rank and step, ~0.1 ms on xGMI against a 170 ms network evaluation).
    * ``exchange="all_to_all"``: the all-to-all of the north-star design.  A is replicated, so every rank derives
      who sends which rows to whom ON THE DEVICE (no count exchange); only the 2 x world split sizes come to the
-     host (one small copy per step -- ``all_to_all_single`` takes Python split lists), and only rows whose
-     ancestor lives elsewhere travel.  The conditional killing resampler leaves survivors in place up to one global
-     rotation (resamplings.py:85), so the traffic is mostly a contiguous shift between neighbours.
+     host (one small copy per step, overlapped with the gather of the send buffer -- ``all_to_all_single`` takes
+     Python split lists, so a variable-size exchange cannot avoid it; a fixed-capacity exchange would have to carry
+     a whole shard per pair, i.e. the all_gather's bytes), and only rows whose ancestor lives elsewhere travel: about
+     one shard per rank instead of world - 1.  The conditional killing resampler leaves survivors in place up to one
+     global rotation (resamplings.py:85), so the traffic is mostly a contiguous shift between two ranks.
+   * ``exchange="auto"``: all_to_all for rows of at least 4 KB on more than two ranks (the image configurations),
+     all_gather otherwise (the toy's rows are a few bytes: one fixed-shape collective wins).
+
+Every normalisation also yields the step's log-normaliser increment and ESS (fbsmi_normalise_ess) without any
+further collective -- the weights are replicated; ``shards.diagnostics`` holds them after a pass.
 
 After the last step the forced-move index is drawn from the replicated weights and the selected particle is
 broadcast from its owner.  Per-row noise is drawn as a slice of the global draw (``row_slice = (offset, count,
@@ -54,13 +62,23 @@ def gpu_backend():
             return None
         return sb.fused_step(us_src, A_local, v, v_prev, t_prev, key, kwargs["mask_"], pin=pin, row_slice=row_slice)
 
-    return SimpleNamespace(split=ops.split, normalise=ops.normalise, exp=lambda x: ops.math_map("exp", x),
+    def normalise_diag(lw):
+        """(normalised log-weights, logsumexp, ESS) of a step's unnormalised log-weights: fbsmi_normalise_ess."""
+        return ops.normalise(lw, log_space=True, return_lse=True, return_ess=True)
+
+    return SimpleNamespace(split=ops.split, normalise=ops.normalise, normalise_diag=normalise_diag,
+                           exp=lambda x: ops.math_map("exp", x),
                            take_rows=ops.take_rows, set_row=ops.set_row, cond_resampling=killing,
                            force_move=force_move, randint=ops.randint, normal=ops.normal, fused_step=fused_step)
 
 
 class ParticleShards:
     """Slot ownership and the exchanges."""
+
+    # rows of at least this many bytes travel by all_to_all under exchange="auto" (only the rows whose ancestor lives elsewhere
+    # move: under conditional killing that is ~one shard per rank, against world - 1 shards for the all_gather), smaller rows by
+    # all_gather (one collective of fixed shape, no split sizes on the host)
+    AUTO_ROW_BYTES = 4096
 
     def __init__(self, n_total: int, group=None, dist=None, exchange: str = "all_gather"):
         self.dist = dist
@@ -69,15 +87,18 @@ class ParticleShards:
             self.rank = dist.get_rank(group)
         else:
             self.world, self.rank = 1, 0
-        if exchange not in ("all_gather", "all_to_all"):
+        if exchange not in ("all_gather", "all_to_all", "auto"):
             raise ValueError(f"unknown exchange {exchange}")
         self.group, self.exchange = group, exchange
         self.R = int(n_total)
         self.n = -(-self.R // self.world)                      # slots per rank
         self.offset = self.rank * self.n
         self.count = max(0, min(self.n, self.R - self.offset))  # rows this rank really owns
-        if self.R < self.world:
-            raise ValueError(f"an ensemble of {self.R} rows cannot be split over {self.world} ranks")
+        if self.R < self.world or (self.world - 1) * self.n >= self.R:
+            # (with shards of ceil(R / world) slots a trailing rank would own no row at all, e.g. 9 rows over 8 ranks)
+            raise ValueError(f"an ensemble of {self.R} rows cannot be split over {self.world} ranks in shards of "
+                             f"{self.n} slots: rank {self.world - 1} would own no row")
+        self.diagnostics = None                                # per-step (lse, ess) of the last forward pass (device tensors)
         self.bytes_moved = 0                                   # payload this rank received in ancestor exchanges
         # gloo has no device collectives: GPU tensors are staged through the host (multi-rank rehearsals on one GPU box;
         # the production backend is nccl = RCCL, which takes device pointers)
@@ -94,6 +115,13 @@ class ParticleShards:
     @property
     def row_slice(self):
         return (self.offset, self.count, self.R)
+
+    def exchange_for(self, us_local: torch.Tensor) -> str:
+        """The ancestor exchange this ensemble uses: the constructor's choice, or by row size under "auto"."""
+        if self.exchange != "auto":
+            return self.exchange
+        row_bytes = int(np.prod(us_local.shape[1:])) * us_local.element_size()
+        return "all_to_all" if (self.world > 2 and row_bytes >= self.AUTO_ROW_BYTES) else "all_gather"
 
     def owns(self, slot: int) -> bool:
         return self.offset <= int(slot) < self.offset + self.count
@@ -138,10 +166,21 @@ class ParticleShards:
         if self.world == 1:
             return take_rows(us_local, A_full)
         send_rows, splits, order = self.exchange_plan(A_full)
-        sp = splits.cpu().tolist()                                # the one host copy of the step: 2 x world integers
+        # all_to_all_single takes its split sizes as Python lists: 2 x world integers come to the host, the one host copy of
+        # the step.  It is started before the send buffer is gathered and awaited after, so the gather overlaps it.
+        if splits.is_cuda:
+            sp_host = torch.empty(splits.shape, dtype=splits.dtype, pin_memory=True)
+            sp_host.copy_(splits, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            sp_host, ev = splits, None
         rowshape = tuple(us_local.shape[1:])
         send = take_rows(us_local, send_rows.to(torch.int32)).reshape(send_rows.numel(), -1).contiguous()
         send = self._h(send)
+        if ev is not None:
+            ev.synchronize()
+        sp = sp_host.tolist()
         recv = torch.empty((self.count, send.shape[1]), dtype=us_local.dtype, device=send.device)
         self.dist.all_to_all_single(recv, send, output_split_sizes=sp[1], input_split_sizes=sp[0], group=self.group)
         recv = recv.to(us_local.device)
@@ -187,7 +226,18 @@ def forward_pass(key, us_star, bs_star, vs, ts, init_sampler, init_likelihood_lo
     if sh.owns(bs[0]):
         us = be.set_row(us, bs[0] - sh.offset, us_star[0])                           # :152
     lw = init_likelihood_logpdf(vs[0], us, vs[1], row_slice=sh.row_slice, **kwargs)   # :154 (local)
-    log_ws = be.normalise(sh.all_gather_rows(lw), log_space=True)                     # :155 (replicated)
+    diag = []                                      # (logsumexp, ESS) of every normalisation, device scalars (no host sync)
+
+    def normalise(lw_local):
+        full = sh.all_gather_rows(lw_local)
+        if getattr(be, "normalise_diag", None) is None:
+            return be.normalise(full, log_space=True)
+        out, lse, ess = be.normalise_diag(full)
+        diag.append(torch.stack([lse.reshape(()), ess.reshape(())]))
+        return out
+
+    log_ws = normalise(lw)                                                            # :155 (replicated)
+    exchange = sh.exchange_for(us)
     keys = be.split(key_scan, nsteps)                                                 # :157
     closures = (transition_sampler, likelihood_logpdf)
     for k in range(nsteps):                                                           # scan_body :132-148
@@ -195,7 +245,7 @@ def forward_pass(key, us_star, bs_star, vs, ts, init_sampler, init_likelihood_lo
         v, v_prev, t_prev = vs[k + 1], vs[k], ts[k]
         A = be.cond_resampling(key_resampling, be.exp(log_ws), bs[k], bs[k + 1], True)  # :139 (replicated)
         A_local = A[sh.offset:sh.offset + sh.count]
-        if sh.exchange == "all_gather" or sh.world == 1:                              # :140: rows by one collective,
+        if exchange == "all_gather" or sh.world == 1:                                 # :140: rows by one collective,
             us_src, A_src = sh.all_gather_rows(us), A_local                           # gathered through A by the consumer
             if sh.world > 1:
                 sh.bytes_moved += (sh.R - sh.count) * int(np.prod(us.shape[1:])) * us.element_size()
@@ -211,7 +261,10 @@ def forward_pass(key, us_star, bs_star, vs, ts, init_sampler, init_likelihood_lo
             if sh.owns(bs[k + 1]):
                 us = be.set_row(us, bs[k + 1] - sh.offset, us_star[k + 1])            # :143
             lw = likelihood_logpdf(v, us_prev, v_prev, t_prev, **kwargs)              # :145 (local)
-        log_ws = be.normalise(sh.all_gather_rows(lw), log_space=True)                 # :146 (gather + replicated)
+        log_ws = normalise(lw)                                                        # :146 (gather + replicated)
+    # per normalisation (T + 1 of them): the log-normaliser increment logsumexp(lw) (csmc.py:146 / smc.py:145-146 `c`) and
+    # the ESS 1 / sum w^2 -- SURVEY.md 8(b) `out_ess`; replicated on every rank, (T + 1, 2) on the device
+    sh.diagnostics = torch.stack(diag) if diag else None
     return log_ws, us
 
 

@@ -31,10 +31,10 @@ def _eq(a, b, what):
     assert bad.size == 0, f"{what}: {bad.size} of {a.size} differ, first {bad[:4]}: {a.ravel()[bad[:4]]} vs {b.ravel()[bad[:4]]}"
 
 
-def _run(name, n, oracle, dev, nsteps=None):
+def _run(name, n, oracle, dev, nsteps=None, dtype="bf16"):
     from fbs_amd import image_configs, ops
     from oracle import em
-    c = image_configs.make(name, dev, dtype="bf16", nsteps=nsteps)
+    c = image_configs.make(name, dev, dtype=dtype, nsteps=nsteps)
     T = c.cfg["nsteps"]
     c.sb.capture = {}
     rng = np.random.default_rng(1)
@@ -56,9 +56,14 @@ def _run(name, n, oracle, dev, nsteps=None):
     us, A = _np(cap["us"]), _np(cap["A"])
     assert us.shape == (rows, emk.du) and A.shape == (rows,) and A.min() >= 0 and A.max() < rows
     vp, v = _np(cap["v_prev"]).reshape(-1), _np(cap["v"]).reshape(-1)
-    img_bits = _np(cap["img"].reshape(rows, -1).view(torch.int16)).view(np.uint16)
-    _eq(img_bits, em.to_bf16_bits(em.concat(us, A, vp, role)), "network input of the last step")
-    net = em.from_bf16_bits(_np(cap["net"].view(torch.int16)).view(np.uint16))
+    if dtype == "bf16":
+        img_bits = _np(cap["img"].reshape(rows, -1).view(torch.int16)).view(np.uint16)
+        _eq(img_bits, em.to_bf16_bits(em.concat(us, A, vp, role)), "network input of the last step")
+        net = em.from_bf16_bits(_np(cap["net"].view(torch.int16)).view(np.uint16))
+    else:   # the reference's precision: float32 network input and output (fbs/nn/unet.py:85-86)
+        assert cap["img"].dtype == torch.float32 and cap["net"].dtype == torch.float32
+        _eq(_np(cap["img"].reshape(rows, -1)), em.concat(us, A, vp, role), "network input of the last step")
+        net = _np(cap["net"].reshape(rows, -1))
     mode, cx, cs, sd = cap["coef"]
     pin_row, pin_val = cap["pin"]
     assert pin_row == int(bs[T])
@@ -82,3 +87,10 @@ def test_config4_one_gpu_share(oracle, dev):
 
 def test_config5_one_gpu_share(oracle, dev):
     _run("c5", 2048, oracle, dev, nsteps=500)
+
+
+@pytest.mark.parametrize("name,n,nsteps", [("c3", 4096, 40), ("c5", 2048, 12)])
+def test_configs_in_float32_the_references_precision(name, n, nsteps, oracle, dev):
+    """The same sweeps with the network in float32, as the reference computes it (bf16 autocast is this build's fast path):
+    per-step shapes as in the configuration, a reduced number of steps (a float32 step costs about four bf16 ones)."""
+    _run(name, n, oracle, dev, nsteps=nsteps, dtype="f32")

@@ -464,6 +464,37 @@ def test_two_slot_prop_kernel_matches_oracle(tree, oracle, dev, monkeypatch):
                 _eq(_np(got[i][c] if C > 1 else got[i]), want[i], f"N={N} chain {c} {what}")
 
 
+@pytest.mark.parametrize("generic", ["0", "1"])
+@pytest.mark.parametrize("toy,N,T,C,eb", [(toy_2d, 200000, 5, 2, True), (toy_4d, 300001, 4, 1, False), (toy_2d, 1100000, 3, 1, True),
+                                         (toy_31, 1048576 + 4096, 2, 1, True)])
+def test_several_slots_per_thread_kernels(generic, toy, N, T, C, eb, oracle, dev, monkeypatch):
+    """N > 131072: tiles of 1024 / 4096 slots (ITEMS = 4 / 16).  k_lg_heaps + k_lg_propN (lane-major slots, four in flight,
+    searches in lockstep, compact heaps) and the one-slot-after-the-other kernel it replaced (FBSMI_GENERIC_PROP=1): ragged
+    last tiles, the stored path, several chains, du = 3.  Bit-exact."""
+    monkeypatch.setenv("FBSMI_GENERIC_PROP", generic)
+    toy_ = toy()
+    ts = np.linspace(0, 1.0, T + 1)
+    br = _bridge(toy_, ts, dev)
+    om = oracle_model_from(oracle, br)
+    rng = np.random.default_rng(N + T)
+    x0 = rng.normal(size=(C, br.du)).astype(np.float32)
+    bs = rng.integers(0, N, (C, T + 1)).astype(np.int32)
+    bs[0, 1] = N - 1
+    bs[0, 2] = 0
+    keys = oracle.split(oracle.PRNGKey(31), C)
+    sweep = br.sweep_handle(N, eb, False, nchains=C)
+    got = sweep.sweep(keys if C > 1 else keys[0], x0 if C > 1 else x0[0], toy_["y0"], bs if C > 1 else bs[0])
+    v = sweep.views()
+    for c in range(C):
+        want = oracle.gibbs_kernel_lg(om, keys[c], x0[c], toy_["y0"], bs[c], N, eb, False, debug=True)
+        for i, what in enumerate(("x0_next", "us_star_next", "bs_star_next", "acc")):
+            _eq(_np(got[i][c] if C > 1 else got[i]), want[i], f"N={N} chain {c} {what}")
+        _eq(_np(v["us_T"][c] if C > 1 else v["us_T"]), want[4], f"particles chain {c}")
+        _eq(_np(v["lw_T"][c] if C > 1 else v["lw_T"]), want[5], f"log-weights chain {c}")
+    del sweep
+    br._sweeps.clear()
+
+
 def test_toy_sb_gibbs_driver(tmp_path, dev):
     """examples/toy_sb_gibbs.py (counterpart of experiments/sb/gibbs.py: Gibbs on the non-separable Gaussian
     Schrodinger bridge, closure tier with Euler-Maruyama forward paths): runs, stays in the bulk of the GP posterior,

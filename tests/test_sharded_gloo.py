@@ -194,3 +194,11 @@ def test_shards_ragged_split_and_argument_checks():
         sharded.ParticleShards(2, dist=FakeDist(3, 1))
     with pytest.raises(ValueError):
         sharded.ParticleShards(10, exchange="ring")
+    # 9 rows over 8 ranks would leave the last three ranks without rows (shards of 2): refused, not crashed on later
+    with pytest.raises(ValueError, match="would own no row"):
+        sharded.ParticleShards(9, dist=FakeDist(8, 7))
+    # "auto": by row size and world size
+    import torch
+    sh3 = sharded.ParticleShards(30, dist=FakeDist(3, 0), exchange="auto")
+    assert sh3.exchange_for(torch.zeros(10, 2048)) == "all_to_all" and sh3.exchange_for(torch.zeros(10, 4)) == "all_gather"
+    assert sharded.ParticleShards(30, dist=FakeDist(2, 0), exchange="auto").exchange_for(torch.zeros(15, 2048)) == "all_gather"
