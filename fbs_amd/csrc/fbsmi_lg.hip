@@ -528,25 +528,28 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
     if (MODE == 0) { FBSMI_STAMP(14) }
     const float w_max = fbsmi_expf(Mraw - lse);  // == max_i w_i: fbsmi_expf is monotone
     const float w_k = MODE == 1 ? fbsmi_expf(l_ref - lse) : 0.0f;
-    float xw[ITEMS], xj[ITEMS], ln[ITEMS];
+    float xw[ITEMS], xj[ITEMS];
     const float inv_n = 1.0f / (float)d.N;   // PUB: N is a power of two, x / N == x * (1 / N) exactly
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int e = base + i;
         xw[i] = 0.0f;
         xj[i] = 0.0f;
-        ln[i] = 0.0f;
-        if (e < d.N) {
-            ln[i] = l[i] - lse;
-            const float w = fbsmi_expf(ln[i]);
+        const bool in = e < d.N;
+        l[i] = in ? l[i] - lse : 0.0f;       // from here on: the normalised log-weight
+        if (in) {
+            const float w = fbsmi_expf(l[i]);
             xw[i] = w;
             if (MODE == 0) xj[i] = e == i_ref ? 0.0f : (PUB ? jprob_pow2(w, w_max, inv_n) : jprob_at(w, w_max, d.N));
             if (MODE == 1) xj[i] = fm_rest_at(w, w_k, e == i_ref, d.N);
         }
+        // several elements per thread: left alone, the scheduler interleaves all sixteen float64 exponentials and their
+        // divisions and the kernel needs 510 registers (one wave per SIMD; measured 273 us for 8M elements).  Four at a time.
+        if (ITEMS > 4 && (i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     chunk_store<ITEMS>(d.w, base, d.N, xw);
-    if (MODE != 0) chunk_store<ITEMS>(d.lwn, base, d.N, ln);   // read back only after the final normalisation (view 1)
-    if (d.lwss) chunk_store<ITEMS>(d.lwss + (size_t)s * d.N, base, d.N, ln);
+    if (MODE != 0) chunk_store<ITEMS>(d.lwn, base, d.N, l);   // read back only after the final normalisation (view 1)
+    if (d.lwss) chunk_store<ITEMS>(d.lwss + (size_t)s * d.N, base, d.N, l);
     float s2[2] = {chunk_total<ITEMS>(xw), chunk_total<ITEMS>(xj)}, t2[2];
     TreePath p2[2];
     block_upsweep_n<2>(s2, p2, xch[2], t2);
@@ -1026,6 +1029,178 @@ __global__ void __launch_bounds__(kBlock) k_lg_propN(LgDev dd, int s) {
         for (int k = 0; k < B; ++k) {
 #pragma unroll
             for (int r = 0; r < DMAX; ++r) u[k][r] = r < d.du ? up[(size_t)r * N + a[k]] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const bool pinned = m[k] == j_ref;
+            float l = -__builtin_inff();
+            if (live[k]) {
+                if (d.As) d.As[(size_t)s * N + m[k]] = a[k];
+                // transition_sampler (gp_gibbs.py:120-122) and the pin of csmc.py:143
+#pragma unroll
+                for (int r = 0; r < DMAX; ++r) {
+                    if (r < d.du) {
+                        const float dr = drift_row<DMAX>(t, r, u[k], v_prev);
+                        float x = (u[k][r] + dr * t.dt) + t.sd * xi[k][r];
+                        if (pinned) x = ustar[r];
+                        un[(size_t)r * N + m[k]] = x;
+                        if (d.uss) d.uss[((size_t)(s + 1) * N + m[k]) * d.du + r] = x;
+                    }
+                }
+                l = lg_loglik<DMAX>(t, u[k], v, v_prev);   // likelihood_logpdf on the gathered particle (csmc.py:145)
+                d.lw[m[k]] = l;
+            }
+            lvs[(i0 + k) * kBlock + threadIdx.x] = l;
+        }
+    }
+    __syncthreads();
+    float lv[ITEMS];
+    if (ITEMS % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i += 4) {
+            const float4 q4 = *reinterpret_cast<const float4*>(lvs + threadIdx.x * ITEMS + i);
+            lv[i] = q4.x; lv[i + 1] = q4.y; lv[i + 2] = q4.z; lv[i + 3] = q4.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) lv[i] = lvs[threadIdx.x * ITEMS + i];
+    }
+    float mx, sx;
+    block_lse_partial<ITEMS>(lv, xch[0], xch[1], mx, sx);
+    if (threadIdx.x == 0) {
+        d.bmax[blockIdx.x] = mx;
+        d.bsumexp[blockIdx.x] = sx;
+    }
+}
+
+// The same with the killed sources' searches COMPACTED: only ~1 - mean(w) / max(w) of the slots are killed (a few per cent
+// when the weights are as flat as a short Euler step leaves them), yet in k_lg_propN every wave walks the 11 LDS levels and
+// the four probe rounds for every one of its slots, because some lane of it usually has a killed one -- a third of that
+// kernel's instructions.  Here the kill tests run first (phase 1) and push the killed slots of the tile into an LDS queue
+// (one LDS atomic per wave and batch); phase 2 hands the queue out one entry per thread -- redraw uniform, LDS levels,
+// probe rounds, all lanes busy --; phase 3 gathers, propagates and weights.  The ancestors found in phase 2 wait in the
+// LDS array that afterwards carries the new log-weights to the chunk-ordered reduction (same owner thread per element).
+template <int ITEMS, int DMAX>
+__global__ void __launch_bounds__(kBlock) k_lg_propQ(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    constexpr int B = ITEMS < 4 ? ITEMS : 4;       // slots in flight per thread
+    constexpr int TILE = kBlock * ITEMS;
+    static_assert(TILE <= 65536 && ITEMS <= 32, "queue entries are 16-bit local slots, kill flags one 32-bit word");
+    __shared__ float xch[2][4];
+    __shared__ __attribute__((aligned(16))) float heapW[kHeapSizeW];
+    __shared__ float heapJ[kHeapSizeJ];
+    __shared__ float win[kBlock];
+    __shared__ __attribute__((aligned(16))) float lvs[TILE];
+    __shared__ uint16_t queue[TILE];
+    __shared__ int qn;
+    const int N = d.N;
+    const uint32_t* kt = d.keytab + 8 * s;
+    const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], t0 = kt[6], t1 = kt[7];
+    const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
+    const int tile0 = blockIdx.x * TILE;
+    const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
+    float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
+    // ---- round 0
+    const float lastJ = d.cdfJ[N - 1];
+    const float last = d.cdf[N - 1];
+    const float w_max = d.scal[1];
+    static_assert(kHeapSizeW == 8 * kBlock && kHeapSizeJ == kBlock, "heap staging assumes 2048 / 256 nodes");
+    const float4 hw0 = reinterpret_cast<const float4*>(d.hpW)[2 * threadIdx.x];
+    const float4 hw1 = reinterpret_cast<const float4*>(d.hpW)[2 * threadIdx.x + 1];
+    const float hj = d.hpJ[threadIdx.x];
+    const StepTables<DMAX> t = step_tables<DMAX>(d, s);
+    const float* v_prev = d.vs + (size_t)s * d.dv;
+    const float* v = d.vs + (size_t)(s + 1) * d.dv;
+    const float* ustar = d.us_star + (size_t)(s + 1) * d.du;
+    const float u3 = __uint_as_float(kt[4]);
+    reinterpret_cast<float4*>(heapW)[2 * threadIdx.x] = hw0;
+    reinterpret_cast<float4*>(heapW)[2 * threadIdx.x + 1] = hw1;
+    heapJ[threadIdx.x] = hj;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    // ---- round 1: J = choice(key_3, N, (), p=J_prob) (resamplings.py:84); roll by j - J (:85)
+    const int J = bisect_uniform(d.cdfJ, N, d.levels, d.lh_j, heapJ, win, lastJ * (1.0f - u3));
+    int shift = (j_ref - J) % N;
+    if (shift < 0) shift += N;
+    // ---- phase 1: the kill tests (resamplings.py:71), the sources' weights rotated but contiguous
+    uint32_t kmask = 0;
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int i0 = 0; i0 < ITEMS; i0 += B) {
+        int src[B];
+        bool live[B];
+        float ws[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const int m = tile0 + (i0 + k) * kBlock + (int)threadIdx.x;
+            live[k] = m < N;
+            int sc = m - shift;
+            if (sc < 0) sc += N;
+            src[k] = live[k] ? sc : 0;
+            ws[k] = d.w[src[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const float u1 = uniform_at(a0, a1, (uint64_t)N, (uint64_t)src[k]);
+            const bool killed = live[k] && (u1 * w_max >= ws[k]);
+            kmask |= (killed ? 1u : 0u) << (i0 + k);
+            const unsigned long long bal = __ballot(killed);
+            if (bal) {   // wave-uniform
+                const int first = __ffsll((long long)bal) - 1;
+                int qb = 0;
+                if (lane == first) qb = atomicAdd(&qn, __popcll(bal));
+                qb = __shfl(qb, first);
+                if (killed) queue[qb + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)((i0 + k) * kBlock + (int)threadIdx.x);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: one queue entry per thread: the redraw from Cat(w) (:73-74)
+    const int nq = qn;
+    int* anc = reinterpret_cast<int*>(lvs);
+#pragma unroll 1
+    for (int e0 = 0; e0 < nq; e0 += kBlock) {
+        const int e = e0 + (int)threadIdx.x;
+        const bool on[1] = {e < nq};
+        const int slot = on[0] ? (int)queue[e] : 0;
+        int sc = tile0 + slot - shift;
+        if (sc < 0) sc += N;
+        const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)(on[0] ? sc : 0));
+        const float qK[1] = {last * (1.0f - u2)};
+        int lo[1], hi[1];
+        bisect_lds_levels(N, d.lh_w, heapW, qK[0], lo[0], hi[0]);
+#pragma unroll 1
+        for (int rem = d.levels - d.lh_w; rem > 0; rem -= 3) bisect_round3_xn<1>(d.cdf, lo, hi, qK, on);
+        if (on[0]) anc[slot] = hi[0];
+    }
+    __syncthreads();
+    // ---- phase 3: ancestors' rows, Euler-Maruyama, pin, log-weight
+#pragma unroll 1
+    for (int i0 = 0; i0 < ITEMS; i0 += B) {
+        int m[B], a[B];
+        bool live[B];
+        float u[B][DMAX], xi[B][DMAX];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const int slot = (i0 + k) * kBlock + (int)threadIdx.x;
+            m[k] = tile0 + slot;
+            live[k] = m[k] < N;
+            int sc = m[k] - shift;
+            if (sc < 0) sc += N;
+            const bool killed = (kmask >> (i0 + k)) & 1u;
+            const int red = anc[slot];                 // (garbage unless killed)
+            a[k] = !live[k] ? 0 : (m[k] == j_ref ? i_ref : (killed ? red : sc));          // :86
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r) u[k][r] = r < d.du ? up[(size_t)r * N + a[k]] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+#pragma unroll
+            for (int r = 0; r < DMAX; ++r)
+                xi[k][r] = r < d.du ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)(live[k] ? m[k] : 0) * d.du + r) : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < B; ++k) {
@@ -3003,6 +3178,44 @@ using namespace fbsmi;
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// The pinned launches (LgDev.pin, FBSMI_WIDE_PIN) rest on an OBSERVED dispatch order -- workgroups are dealt round-robin over
+// the eight XCDs, so blocks b and b + 8 share one -- that HIP does not promise.  It is checked once per process on the
+// hardware itself: a 64-block probe launch reads HW_REG_XCC_ID in every block; pinning stays on only if blocks of equal
+// b % 8 all report the same XCD and the eight classes report eight different ones.  (Results never depend on it: a pinned
+// launch only chooses WHICH blocks do the work.)  FBSMI_PIN_CHECK=0 skips the probe and trusts the order.
+__global__ void k_xcc_probe(int* out) {
+    if (threadIdx.x == 0) {
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        out[blockIdx.x] = (int)(id & 15);
+    }
+}
+
+static bool xcd_round_robin_holds() {
+    static const int ok = [] {
+        if (const char* e = getenv("FBSMI_PIN_CHECK"))
+            if (atoi(e) == 0) return 1;
+        constexpr int kProbeBlocks = 64;
+        int* dev = nullptr;
+        int host[kProbeBlocks];
+        if (hipMalloc(&dev, sizeof(host)) != hipSuccess) return 0;
+        bool good = hipMemset(dev, 0xff, sizeof(host)) == hipSuccess;
+        if (good) {
+            k_xcc_probe<<<kProbeBlocks, 64, 0, nullptr>>>(dev);
+            good = hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        (void)hipFree(dev);
+        if (!good) return 0;
+        unsigned seen = 0;
+        for (int b = 0; b < kProbeBlocks; ++b) {
+            if (host[b] < 0 || host[b] > 15 || host[b] != host[b & 7]) return 0;
+            if (b < 8) seen |= 1u << host[b];
+        }
+        return __builtin_popcount(seen) == 8 ? 1 : 0;
+    }();
+    return ok != 0;
+}
+
 struct fbsmi_lg_sweep {
     LgDev d{};
     int items = 1, dmax = 2;
@@ -3138,7 +3351,7 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     for (int k = 0; one_tile && !persistent && k < d.T; ++k) {
         ProfScope p(s, 2, st);
         if (d.wide) {
-            static const int pin = [] { const char* e = getenv("FBSMI_WIDE_PIN"); return e ? atoi(e) : 1; }();
+            static const int pin = [] { const char* e = getenv("FBSMI_WIDE_PIN"); return (e ? atoi(e) : 1) && xcd_round_robin_holds(); }();
             if (pin && d.C == 1 && gwide.x <= 32)
                 k_lgw_gemm<1><<<dim3(gwide.x * 8, 1), kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 8 + ((2 * d.c0) & 7));
             else k_lgw_gemm<1><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
@@ -3193,7 +3406,9 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
             } else if (s->items > 1 && !s->generic_prop) {
                 // several slots per thread: compact heaps by their own small launch, then the batched kernel
                 k_lg_heaps<<<dim3(kHeapSizeW / kBlock, d.C), kBlock, 0, st>>>(d);
-                LG_DISPATCH(s, (k_lg_propN<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
+                static const int queue = [] { const char* e = getenv("FBSMI_BIGN_QUEUE"); return e ? atoi(e) : 1; }();
+                if (queue) LG_DISPATCH(s, (k_lg_propQ<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
+                else LG_DISPATCH(s, (k_lg_propN<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
             } else {
                 LG_DISPATCH(s, (k_lg_prop<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, k)));
             }
@@ -3390,6 +3605,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         const int64_t pin_max = pm ? atoi(pm) : 64;   // two workgroups per CU of the XCD: measured better up to there, worse beyond
         d.pin = (s->tree_step && !s->generic_prop && s->tree_halves < 0 && s->two_slot_prop < 0 && (int64_t)d.nb * C <= pin_max &&
                  (int64_t)d.nb * C < 2 * 256 && !(pe && atoi(pe) == 0)) ? 1 : 0;
+        if (d.pin && !xcd_round_robin_holds()) d.pin = 0;   // the dispatch order the pinning rests on is not what this machine does
     }
     rc |= slab_request(s, &d.bsumw, C * d.nb);
     rc |= slab_request(s, &d.bsumJ, C * d.nb);
@@ -3430,6 +3646,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         fbsmi_lg_sweep_destroy(s);
         return FBSMI_ERR_HIP;
     }
+    (void)xcd_round_robin_holds();   // the once-per-process placement probe must not run inside a later stream capture
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming) != hipSuccess) {
@@ -3673,7 +3890,7 @@ int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
             return FBSMI_OK;
         }
         // one-tile ensembles: a step's launches are a few dozen workgroups -- pinned to one XCD (bit 8 of `emit`, grids 8x wide)
-        static const int pin_on = [] { const char* e = getenv("FBSMI_WIDE_PIN"); return e ? atoi(e) : 1; }();
+        static const int pin_on = [] { const char* e = getenv("FBSMI_WIDE_PIN"); return (e ? atoi(e) : 1) && xcd_round_robin_holds(); }();
         const bool pinw = pin_on && d.C == 1 && nst * nrt <= 32;
         const int pe = pinw ? 0x100 : 0, pg = pinw ? 8 : 1;
         if (d.flow == 0) {

@@ -419,3 +419,36 @@ def test_whole_network_against_the_numpy_restatement_of_the_flax_unet(shape, dim
     with torch.no_grad():
         got = net(x, 0.5).numpy().reshape(shape)
     np.testing.assert_allclose(got, unet_np.forward(flat2, x.numpy(), 0.5, 2.0 / 200, dim), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 16, 16, 1), (2, 16, 16, 3)])
+def test_whole_network_hip_inference_path_against_the_numpy_restatement(shape):
+    """The GPU inference path at the configurations' width (dim 64: the MFMA convolution / qkv-attention / 64-channel
+    projection kernels and the normalisation kernels are all engaged) directly against oracle/unet_np.py, the float64 numpy
+    restatement of the flax UNet -- not only against the eager torch module.  Tolerances per arithmetic: float32 (the
+    reference's precision; MIOpen / hipBLASLt accumulate in another order than numpy) 1e-3 of the output scale; bf16 autocast
+    (inputs and weights of every matrix product rounded to 8 significant bits, float32 accumulation, ~60 layers) 6e-2."""
+    from oracle import unet_np
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, H, W, C = shape
+    dim = 64
+    net = UNet(dt=2.0 / 200, dim=dim, in_channels=C, upsampling="pixel_shuffle", dim_mults=(1, 2, 4)).eval()
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.add_(0.02 * torch.randn_like(p_))
+    flat = net.export_flat_params().numpy()
+    x = torch.randn(*shape)
+    want = unet_np.forward(flat, x.numpy(), 0.37, 2.0 / 200, dim)
+    scale = max(float(np.abs(want).max()), 1.0)
+    net = net.to(dev)
+    xd = x.to(dev)
+    with torch.no_grad():
+        got32 = net(xd, 0.37).float().cpu().numpy().reshape(shape)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got16 = net(xd, 0.37).float().cpu().numpy().reshape(shape)
+    assert np.abs(got32 - want).max() <= 1e-3 * scale, np.abs(got32 - want).max() / scale
+    assert np.abs(got16 - want).max() <= 6e-2 * scale, np.abs(got16 - want).max() / scale
+    # the bf16 error is rounding noise, not a convention slip: it is small on average too
+    assert np.abs(got16 - want).mean() <= 1.5e-2 * scale
