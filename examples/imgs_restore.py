@@ -3,7 +3,9 @@
 Counterpart of the reference drivers experiments/imgs/inpainting.py and experiments/imgs/supr.py (they differ by the
 mask only; here `--task inpaint` / `--task supr`) and, with `--sb`, of experiments/sb_imgs/supr.py: same command-line
 flags, same key schedule, same result arrays (`*-gibbs-eb-ef.npy`, `*-filter.npy`, `*-pmcmc-<delta>.npy` of shape
-(nsamples, H, W, C)), written against fbs_amd.  The closures are the bound methods of one fbs_amd.score.ScoreBridge, so
+(nsamples, H, W, C)), written against fbs_amd.  `--method twisted` is experiments/imgs/inpainting_twisted.py (the twisted-SMC
+baseline: whole-image particles, the twisting function's gradient through the score network by torch.autograd; result
+`*-twisted.npy`).  The closures are the bound methods of one fbs_amd.score.ScoreBridge, so
 every SMC step is two HIP kernels around one network evaluation (PyTorch-ROCm).
 
 The reference loads a trained checkpoint (`./checkpoints/<dataset>_<sde>_<epoch>.npz`, a flat `param` / `ema_param`
@@ -45,7 +47,7 @@ def main(argv=None):
     p.add_argument('--start_from', type=int, default=0)
     p.add_argument('--nparticles', type=int, default=100)
     p.add_argument('--nsamples', type=int, default=100)
-    p.add_argument('--method', type=str, default='gibbs-eb-ef', help="'filter', 'gibbs[-eb][-ef]', 'pmcmc[-delta]'.")
+    p.add_argument('--method', type=str, default='gibbs-eb-ef', help="'filter', 'gibbs[-eb][-ef]', 'pmcmc[-delta]', 'twisted'.")
     p.add_argument('--init_method', type=str, default='filter')
     p.add_argument('--marg', action='store_true', default=False, help='Whether marginalise out the Y path.')
     p.add_argument('--dim', type=int, default=64, help='UNet width (64 in the reference).')
@@ -139,6 +141,23 @@ def main(argv=None):
                 if not args.quiet:
                     print(f'{task} | Gibbs | iter: {i}, acc: {float(acc.float().mean()):.3f}')
             np.save(head + f'-gibbs{"-eb" if eb else ""}{"-ef" if ef else ""}{"-marg" if args.marg else ""}', restored)
+        elif args.method == 'twisted':                                               # inpainting_twisted.py:148-191
+            from fbs_amd.twisted import make_image_twisted
+
+            def score(uv, t):                                                        # differentiable: no no_grad here
+                if args.fp32:
+                    return net(uv, t).reshape(uv.shape)
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    return net(uv, t).float().reshape(uv.shape)
+
+            tw = make_image_twisted(score, ds, sde, ts, args.nparticles)
+            for i in range(args.nsamples):
+                key, subkey = ops.split(key)
+                sample = tw.conditional_sampler(subkey, test_y0, stratified, mask_=mask)
+                restored[i] = sample.cpu().numpy()
+                if not args.quiet:
+                    print(f'{task} | twisted | iter: {i}')
+            np.save(head + '-twisted', restored)
         elif 'pmcmc' in args.method:
             key, subkey = ops.split(key)
             x0, log_ell, ys = torch.zeros(x_shape, device=dev), 0., sb.fwd_ys_sampler(subkey, test_y0)

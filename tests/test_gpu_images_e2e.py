@@ -96,6 +96,7 @@ def test_sharded_world1_equals_unsharded_with_unet(oracle, dev):
     ["--task", "supr", "--rate", "4", "--method", "filter"],
     ["--task", "inpaint", "--rect_size", "8", "--method", "pmcmc-0.005"],
     ["--task", "supr", "--rate", "4", "--sb", "--method", "gibbs"],
+    ["--task", "inpaint", "--rect_size", "15", "--method", "twisted"],
 ])
 def test_image_drivers_run_end_to_end(argv, tmp_path, dev):
     """examples/imgs_restore.py: the counterparts of experiments/imgs/inpainting.py, supr.py and experiments/sb_imgs/supr.py
@@ -107,4 +108,53 @@ def test_image_drivers_run_end_to_end(argv, tmp_path, dev):
                                     "--chunk", "8", "--fp32", "--quiet", "--outdir", str(tmp_path)])
     assert out.shape == (2, 28, 28, 1) and np.isfinite(out).all()
     files = sorted(os.listdir(tmp_path))
-    assert any(f.endswith("-true.npz") for f in files) and any(("gibbs" in f or "filter" in f or "pmcmc" in f) and f.endswith(".npy") for f in files)
+    assert any(f.endswith("-true.npz") for f in files) and any(("gibbs" in f or "filter" in f or "pmcmc" in f or "twisted" in f) and f.endswith(".npy") for f in files)
+
+
+def test_image_twisted_closures_closed_form_and_driver_pieces(oracle, dev):
+    """fbs_amd/twisted.py (experiments/imgs/inpainting_twisted.py:97-154) with a LINEAR stand-in score s(x, t) = -c x, for which
+    everything has a closed form: the one-step denoising estimate is kappa x with kappa = 1 + dt (0.5 beta + beta (-c)), so the
+    gradient of the twisting log-density that autograd sends through the score is kappa (y - kappa x) / s^2 on the observed
+    pixels and 0 elsewhere; the proposal's mean, its log-density and the weights of twisted_smc follow.  Then one run of
+    twisted_smc itself (stratified resampling: libfbsmi) on whole-image particles."""
+    import math
+    from fbs_amd import ops
+    from fbs_amd.images import ImageRestore
+    from fbs_amd.samplers import stratified
+    from fbs_amd.sdes import StationaryLinLinearSDE, make_linear_sde
+    from fbs_amd.twisted import make_image_twisted
+    Tend, T, n, c = 2.0, 8, 16, 0.7
+    ts = np.linspace(0, Tend, T + 1)
+    sde = StationaryLinLinearSDE(beta_min=0.02, beta_max=5.0, t0=0.0, T=Tend)
+    ds = ImageRestore("inpaint-5", (12, 12, 2), device=dev)
+    mask = ds.gen_mask(oracle.PRNGKey(4))
+    tw = make_image_twisted(lambda x, t: -c * x, ds, sde, ts, n)
+    rng = np.random.default_rng(0)
+    uv = torch.from_numpy(rng.normal(size=(n, 12, 12, 2)).astype(np.float32)).to(dev)
+    y = torch.from_numpy(rng.normal(size=tuple(ds.unpack(uv[0], mask)[1].shape)).astype(np.float32)).to(dev)
+    t = float(ts[3])
+    dt = Tend / T
+    beta = sde.beta(Tend - t)
+    kappa = 1.0 + dt * (0.5 * beta - beta * c)
+    F, Q = make_linear_sde(sde)[0](Tend - t, 0.0)
+    s2 = float(F) ** 2 * 0.06 + float(Q)
+    grad = torch.zeros_like(uv).reshape(n, 144, 2)
+    obs = ds.unpack(uv, mask)[1]
+    grad[:, mask.obs_inds_ravelled] = kappa * (y.unsqueeze(0) - kappa * obs) / s2
+    want_cd = (0.5 * beta - beta * c) * uv + beta * grad.reshape(uv.shape)
+    got_cd = tw.reverse_cond_drift(uv, t, y, mask)
+    assert torch.allclose(got_cd, want_cd, rtol=2e-5, atol=2e-5), (got_cd - want_cd).abs().max().item()
+    want_tw = (-0.5 * (y.unsqueeze(0) - kappa * obs) ** 2 / s2 - 0.5 * math.log(2 * math.pi * s2)).reshape(n, -1).sum(1)
+    assert torch.allclose(tw.twisting_logpdf(y, uv, t, mask_=mask), want_tw, rtol=2e-5, atol=1e-3)
+    # proposal: mean + sqrt(dt) b z with z = jax.random.normal(key, (n, w, h, c)) drawn by libfbsmi
+    key = oracle.PRNGKey(9)
+    z = torch.from_numpy(oracle.normal(key, (n, 12, 12, 2))).to(dev)
+    want_prop = (uv + want_cd * dt) + math.sqrt(dt) * math.sqrt(beta) * z
+    got_prop = tw.twisting_prop_sampler(key, uv, t, y, mask_=mask)
+    assert torch.allclose(got_prop, want_prop, rtol=2e-5, atol=2e-5)
+    lp = tw.twisting_prop_logpdf(got_prop, uv, t, y, mask_=mask)
+    want_lp = (-0.5 * z.double() ** 2 - 0.5 * math.log(2 * math.pi * dt * beta)).reshape(n, -1).sum(1)
+    assert torch.allclose(lp.double(), want_lp, rtol=1e-4, atol=5e-2)
+    # the whole filter + the final categorical draw
+    out = tw.conditional_sampler(oracle.PRNGKey(11), y, stratified, mask_=mask)
+    assert out.shape == (12, 12, 2) and torch.isfinite(out).all()
