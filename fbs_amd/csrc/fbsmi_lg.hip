@@ -507,6 +507,20 @@ __device__ __forceinline__ float tree_left_sum(const TreePath p, int i) {   // b
     return v;
 }
 
+// the sum of the block of 2^lv leaves next to this thread's own block of 2^lv leaves (its sibling in the tile's tree):
+// levels 0..5 inside the wave, 6 the other wave of the pair, 7 the other pair of waves
+__device__ __forceinline__ float tree_sibling_sum(const TreePath& p, int lv) {
+    if (lv < 7) return p.ls[lv];
+    return (threadIdx.x & 128) ? p.ls[7] : p.hi;
+}
+
+// the tile's tree sum when the leaf of the thread that recorded `sib` (its eight sibling sums, leaf level first) holds x
+__device__ __forceinline__ float tree_fold(float x, const float (&sib)[8], int levels = 8) {
+#pragma unroll
+    for (int lv = 0; lv < 8; ++lv) x = lv < levels ? x + sib[lv] : x;
+    return x;
+}
+
 template <int ITEMS, int MODE, bool PUB = false>
 __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
     int bx = blockIdx.x;
@@ -554,6 +568,14 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
     TreePath p2[2];
     block_upsweep_n<2>(s2, p2, xch[2], t2);
     if (PUB && ITEMS == 1) {   // the tile's part of the summation tree, for the tree-walking searches of k_lg_prop1t
+        if (MODE == 0 && base == i_ref) {
+            // The J_prob leaf of the reference index is 0 here and becomes J_prob[i*] = 1 - (sum of the others) once every
+            // tile's sum is known (resamplings.py:80-82).  A changed leaf changes the tree sums on its path only, and each of
+            // them is (sum below) + (sibling's sum): this thread's eight sibling sums are all the next kernel needs to redo
+            // the tile's sum for ANY value of that leaf -- it no longer fetches the tile and re-reduces it.
+#pragma unroll
+            for (int lv = 0; lv < 8; ++lv) d.scal[4 + lv] = tree_sibling_sum(p2[1], lv);
+        }
         const int i = threadIdx.x;
         if ((i & 3) == 0) {   // the midpoints of the nodes of 8 leaves and more: 64 threads, 16 per wave
             const int h = i ? tree_mid_node(i) : 0;
@@ -1289,7 +1311,8 @@ __device__ __forceinline__ int tree_walk_n(const float2* heap, int h, int levels
 
 // what a workgroup of the two-launch step loads at entry for the trees (issued before the noise draws)
 struct TreeEntry {
-    float sw, sj, wf, wr;   // tile `tid`: sum of w, sum of J_prob ([i*] = 0), w of its first element; w of the tile of i*
+    float sw, sj, wf;       // tile `tid`: sum of w, sum of J_prob ([i*] = 0), w of its first element
+    float refsib[8];        // sibling sums of the leaf i* in its tile's J_prob tree (published by k_lg_norm)
     float4 stg[kMidN / 2];  // this thread's part of trWtop
 };
 
@@ -1300,7 +1323,8 @@ __device__ __forceinline__ TreeEntry tree_entry_loads(const LgDev& d, int i_ref)
     e.sw = tl ? d.bsumw[tid] : 0.0f;
     e.sj = tl ? d.bsumJ[tid] : 0.0f;
     e.wf = tl ? d.wfirst[tid] : 0.0f;
-    e.wr = d.w[(i_ref / kBlock) * kBlock + tid];
+#pragma unroll
+    for (int lv = 0; lv < 8; ++lv) e.refsib[lv] = d.scal[4 + lv];
 #pragma unroll
     for (int k = 0; k < kMidN / 2; ++k) {
         const int idx = tid + kBlock * k;
@@ -1313,11 +1337,12 @@ __device__ __forceinline__ TreeEntry tree_entry_loads(const LgDev& d, int i_ref)
 // first three levels of every tile's w heap
 struct TreeLds {
     float xch[5][4];
+    float bc[8];   // sibling sums of the tile of i* in the tree over the tiles (broadcast by the thread that owns that tile)
     __attribute__((aligned(16))) float2 topW[kBlock], topJ[kBlock], tileJ[kBlock];
     __attribute__((aligned(16))) float2 midW[kMidN * kBlock];
 };
 
-constexpr int kTreeBuildBarriers = 6;   // __syncthreads() executed by tree_build (four up-sweep exchanges, two explicit)
+constexpr int kTreeBuildBarriers = 5;   // __syncthreads() executed by tree_build (two up-sweep exchanges, three explicit)
 
 // Builds the heaps and finds J = choice(key_3, N, (), p=J_prob) (resamplings.py:84), the same in every thread;
 // `last` = cdf[N - 1].  Ends with every heap visible to the workgroup.
@@ -1338,18 +1363,27 @@ __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, Tr
     last = t2[0];                                  // == cdf[N - 1]
     const float Ji = fmaxf(1.0f - t2[1], 0.0f);    // J_prob[i*] (resamplings.py:80-82)
     if (tid) L.topW[g] = make_float2(tree_left_sum(p2[0], tid), e.wf);
-    // the tile that holds i*: its tree sum changes
-    float s1[1], t1s[1];
-    TreePath p1[1];
-    s1[0] = b_ref * kBlock + tid == i_ref ? Ji : jprob_pow2(e.wr, w_max, inv_n);
-    block_upsweep_n<1>(s1, p1, L.xch[2], t1s);
-    const float tile_ref = t1s[0];
-    s1[0] = tid == b_ref ? tile_ref : e.sj;
-    block_upsweep_n<1>(s1, p1, L.xch[3], t1s);
-    const float lastJ = t1s[0];                    // == cdfJ[N - 1]
+    // the tile that holds i*: its leaf changes from 0 to Ji, so the tile's sum is redone along the leaf's path ...
+    const float tile_ref = tree_fold(Ji, e.refsib);
+    // ... and so is the tree over the tiles along the path of leaf b_ref: the thread that owns that leaf hands out its
+    // sibling sums (one barrier instead of two further up-sweeps)
+    if (tid == b_ref) {
+#pragma unroll
+        for (int lv = 0; lv < 8; ++lv) L.bc[lv] = tree_sibling_sum(p2[1], lv);
+    }
+    __syncthreads();
+    float bsib[8];
+#pragma unroll
+    for (int lv = 0; lv < 8; ++lv) bsib[lv] = L.bc[lv];
+    const float lastJ = tree_fold(tile_ref, bsib);   // == cdfJ[N - 1]
     if (tid) {
+        // node g: leaves [tid - 2^c, tid + 2^c), c = ctz(tid); its left half holds b_ref iff tid - 2^c <= b_ref < tid, and then
+        // the half's sum is the fold of the new leaf over the first c levels of that path
+        const int c = __builtin_ctz(tid);
+        const bool hit = b_ref < tid && b_ref >= tid - (1 << c);
+        const float left = hit ? tree_fold(tile_ref, bsib, c) : tree_left_sum(p2[1], tid);
         const float jf = tid * kBlock == i_ref ? Ji : (tid < nb ? jprob_pow2(e.wf, w_max, inv_n) : 0.0f);
-        L.topJ[g] = make_float2(tree_left_sum(p1[0], tid), jf);
+        L.topJ[g] = make_float2(left, jf);
     }
     __syncthreads();
     // ---- the walk for J.  The interval of the bisection is the node itself ([lo, hi) = the node's leaves), so the
@@ -1360,6 +1394,8 @@ __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, Tr
     int h = tree_walk_n(L.topJ, kBlock / nb, top_levels, q, P, E);
     const int lo0 = (h - kBlock) * kBlock;   // first slot of the tile the walk arrived at
     const float wj = d.w[lo0 + tid];
+    float s1[1], t1s[1];
+    TreePath p1[1];
     s1[0] = lo0 + tid == i_ref ? Ji : jprob_pow2(wj, w_max, inv_n);
     const float xj = s1[0];
     block_upsweep_n<1>(s1, p1, L.xch[4], t1s);
