@@ -1342,7 +1342,7 @@ struct TreeLds {
     __attribute__((aligned(16))) float2 midW[kMidN * kBlock];
 };
 
-constexpr int kTreeBuildBarriers = 5;   // __syncthreads() executed by tree_build (two up-sweep exchanges, three explicit)
+constexpr int kTreeBuildBarriers = 4;   // __syncthreads() executed by tree_build (two up-sweep exchanges, two explicit)
 
 // Builds the heaps and finds J = choice(key_3, N, (), p=J_prob) (resamplings.py:84), the same in every thread;
 // `last` = cdf[N - 1].  Ends with every heap visible to the workgroup.
@@ -1359,22 +1359,38 @@ __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, Tr
     const int g = tid ? tree_mid_node(tid) : 0;
     float s2[2] = {e.sw, e.sj}, t2[2];
     TreePath p2[2];
-    block_upsweep_n<2>(s2, p2, L.xch[0], t2);
+    // block_upsweep_n<2>, with one more thing riding on its exchange: the thread that owns the tile of i* hands out the
+    // sibling sums of that leaf (levels inside its wave; the two levels across waves follow from the wave totals)
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        s2[0] = wave_upsweep(s2[0], p2[0]);
+        s2[1] = wave_upsweep(s2[1], p2[1]);
+        if (lane == 0) {
+            L.xch[0][wave] = s2[0];
+            L.xch[1][wave] = s2[1];
+        }
+        if (tid == b_ref) {
+#pragma unroll
+            for (int lv = 0; lv < 6; ++lv) L.bc[lv] = p2[1].ls[lv];
+        }
+        __syncthreads();
+        t2[0] = waves_combine(L.xch[0][0], L.xch[0][1], L.xch[0][2], L.xch[0][3], s2[0], p2[0]);
+        t2[1] = waves_combine(L.xch[1][0], L.xch[1][1], L.xch[1][2], L.xch[1][3], s2[1], p2[1]);
+    }
     last = t2[0];                                  // == cdf[N - 1]
     const float Ji = fmaxf(1.0f - t2[1], 0.0f);    // J_prob[i*] (resamplings.py:80-82)
     if (tid) L.topW[g] = make_float2(tree_left_sum(p2[0], tid), e.wf);
     // the tile that holds i*: its leaf changes from 0 to Ji, so the tile's sum is redone along the leaf's path ...
     const float tile_ref = tree_fold(Ji, e.refsib);
-    // ... and so is the tree over the tiles along the path of leaf b_ref: the thread that owns that leaf hands out its
-    // sibling sums (one barrier instead of two further up-sweeps)
-    if (tid == b_ref) {
-#pragma unroll
-        for (int lv = 0; lv < 8; ++lv) L.bc[lv] = tree_sibling_sum(p2[1], lv);
-    }
-    __syncthreads();
+    // ... and so is the tree over the tiles along the path of leaf b_ref
     float bsib[8];
+    {
+        const int wb = b_ref >> 6;   // the wave that owns leaf b_ref
 #pragma unroll
-    for (int lv = 0; lv < 8; ++lv) bsib[lv] = L.bc[lv];
+        for (int lv = 0; lv < 6; ++lv) bsib[lv] = L.bc[lv];
+        bsib[6] = L.xch[1][wb ^ 1];
+        bsib[7] = (wb & 2) ? L.xch[1][0] + L.xch[1][1] : L.xch[1][2] + L.xch[1][3];
+    }
     const float lastJ = tree_fold(tile_ref, bsib);   // == cdfJ[N - 1]
     if (tid) {
         // node g: leaves [tid - 2^c, tid + 2^c), c = ctz(tid); its left half holds b_ref iff tid - 2^c <= b_ref < tid, and then
@@ -2443,6 +2459,23 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     FBSMI_STAMP(24)
 }
 
+// The noise of one step of a large wide ensemble, normal(key_transition, (N, du)) (gp_gibbs.py:122), as its own streaming
+// launch: elements a and a + n/2 of the draw are the two words of one Threefry call (jax's random_bits), so a thread that
+// owns a pair draws two normals per block-cipher call -- half the instructions of normal_at per element inside the drift
+// kernel, where four of the seven row tiles of every workgroup spent 2.5 us each on their draws with the matrix cores idle.
+__global__ void __launch_bounds__(kBlock) k_lgw_noise(LgDev dd, int s) {
+    const LgDev d = chain_view(dd, blockIdx.y);
+    const uint32_t t0 = d.keytab[8 * s + 6], t1 = d.keytab[8 * s + 7];
+    const uint32_t n = (uint32_t)d.N * (uint32_t)d.du, half = (n + 1u) >> 1;
+    for (uint32_t a = blockIdx.x * kBlock + threadIdx.x; a < half; a += gridDim.x * kBlock) {
+        const uint32_t b = a + half;
+        uint32_t o0, o1;
+        threefry2x32(t0, t1, a, b < n ? b : 0u, o0, o1);
+        d.xiw[a] = normal_from_bits(o0);
+        if (b < n) d.xiw[b] = normal_from_bits(o1);
+    }
+}
+
 // The same product for LARGE wide ensembles: one workgroup keeps its 32 gathered ancestor rows in LDS and
 // walks ALL row tiles of G_s over them (the gather -- the scattered part -- is paid once instead of once
 // per row tile), the next G tile travelling to registers while the matrix cores work on the current one.
@@ -2456,8 +2489,6 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     const int N = d.N, du = d.du, D = d.D;
     const int ts = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t* kt = d.keytab + 8 * s;
-    const uint32_t t0 = kt[6], t1 = kt[7];
     const int j_ref = d.bs[s + 1];
     const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
     float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
@@ -2543,11 +2574,16 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
         const int row0 = kWideTile * tr + 16 * ar + 4 * (lane >> 4);
         mfma_f4 acc;
         float xi[4];
+        if (vec4) {   // the step's noise was drawn by k_lgw_noise: one 16-byte load, in flight under the products
+            float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 < du && mo < N) x4 = *reinterpret_cast<const float4*>(d.xiw + (size_t)mo * du + row0);
+            xi[0] = x4.x; xi[1] = x4.y; xi[2] = x4.z; xi[3] = x4.w;
+        }
 #pragma unroll
         for (int vv = 0; vv < 4; ++vv) {
             const int r = row0 + vv;
             acc[vv] = r < D ? g[r] : 0.0f;
-            xi[vv] = (r < du && mo < N) ? normal_at(t0, t1, (uint64_t)N * du, (uint64_t)mo * du + r) : 0.0f;
+            if (!vec4) xi[vv] = (r < du && mo < N) ? d.xiw[(size_t)mo * du + r] : 0.0f;
         }
 #pragma unroll 2
         for (int q4 = 0; q4 < (Q >> 2); ++q4) {
@@ -2559,7 +2595,31 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
         }
         if (tr == 0) { FBSMI_STAMP(22) }
         if (tr == 5) { FBSMI_STAMP(26) }
-        if (mo < N) {
+        if (mo < N && vec4) {
+            // the lane's four rows are consecutive and du, D are multiples of four: all four are coordinates, or all four
+            // are observation rows, or none exists -- and each kind leaves as ONE 16-byte store (they were four dword
+            // stores to sixteen different cache lines per instruction)
+            if (row0 < du) {
+                float x[4];
+#pragma unroll
+                for (int vv = 0; vv < 4; ++vv) {
+                    const int r = row0 + vv;
+                    x[vv] = (Zs[jloc * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
+                    if (pinned) x[vv] = ustar[r];
+                }
+                const float4 o4 = make_float4(x[0], x[1], x[2], x[3]);
+                *reinterpret_cast<float4*>(un + (size_t)mo * du + row0) = o4;
+                if (d.uss) *reinterpret_cast<float4*>(d.uss + ((size_t)(s + 1) * N + mo) * du + row0) = o4;
+            } else if (row0 < D) {
+                const int rv0 = row0 - du;
+                const float4 vt = *reinterpret_cast<const float4*>(v + rv0), vp = *reinterpret_cast<const float4*>(v_prev + rv0);
+                const float tg[4] = {vt.x, vt.y, vt.z, vt.w}, pv[4] = {vp.x, vp.y, vp.z, vp.w};
+                float l4[4];
+#pragma unroll
+                for (int vv = 0; vv < 4; ++vv) l4[vv] = norm_logpdf(tg[vv], pv[vv] + acc[vv] * d.dt, sd2, lognorm);
+                *reinterpret_cast<float4*>(d.lpw + (size_t)mo * dvp + rv0) = make_float4(l4[0], l4[1], l4[2], l4[3]);
+            }
+        } else if (mo < N) {
 #pragma unroll
             for (int vv = 0; vv < 4; ++vv) {
                 const int r = row0 + vv;
@@ -3418,8 +3478,12 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
             ProfScope p(s, 2, st);
             if (d.wide) {
                 k_lgw_anc<<<gtile, kBlock, 0, st>>>(d, k);
-                if ((int64_t)gwide.x * d.C > 2048)   // enough workgroups to fill the chip twice over: gather once per slot tile
+                if ((int64_t)gwide.x * d.C > 2048) {   // enough workgroups to fill the chip twice over: gather once per slot tile
+                    const int64_t pairs = ((int64_t)d.N * d.du + 1) / 2;
+                    k_lgw_noise<<<dim3((unsigned)((pairs + kBlock - 1) / kBlock < 4096 ? (pairs + kBlock - 1) / kBlock : 4096), d.C),
+                                  kBlock, 0, st>>>(d, k);
                     k_lgw_gemm_fat<<<dim3((d.N + kWideTile - 1) / kWideTile, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+                }
                 else
                     k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
                 k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);

@@ -250,10 +250,13 @@ class LGSweep:
         # (same results bit for bit; FBSMI_CHAIN_GROUPS=1 keeps one handle, =k asks for k groups).
         G = 1
         if _group is None:
-            # (wide models: four groups -- their sweeps are long enough for the host to feed four graphs; narrow ones: two,
-            # four were measured host-bound, 13.7 against 8.0 ms per sweep)
+            # Two groups, except large wide ensembles (launches of tens of microseconds), which take four.  Four streams of
+            # SHORT dependent launches are pathological on some boxes: round 3 measured 28-31 us per step with four groups of
+            # one chain against 16 with two, for the narrow toy and for the d = 100 toy at 100 particles alike (round 2's box
+            # had run the latter 10 % faster with four); the host is not the limit (0.3 us per graph node), the queues are.
             wide = max(model.du, model.dv) > 16
-            G = int(os.environ.get("FBSMI_CHAIN_GROUPS", "0")) or ((4 if (wide and self.C % 4 == 0) else 2) if self.C >= 4 else 1)
+            G = int(os.environ.get("FBSMI_CHAIN_GROUPS", "0")) or \
+                ((4 if (wide and self.C % 4 == 0 and nparticles >= 4096) else 2) if self.C >= 4 else 1)
             if G < 1 or self.C % G:
                 G = 1
         if G > 1:
