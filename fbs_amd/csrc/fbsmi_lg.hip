@@ -2648,6 +2648,13 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     FBSMI_STAMP(30)
 }
 
+// (Round 3 built the variant this file's history kept describing -- TWO independent accumulator chains per wave: 64-row G
+// tiles, each wave alternating between the accumulators of two row blocks against the same 16 gathered slots, 80 KB of LDS,
+// bit-exact -- and measured it on one box against this kernel: d = 100, N = 10 000, two chain groups 22.5 against 19.4 ms per
+// sweep, N = 100 000 182 against 174 ms.  With two workgroups per CU every SIMD already holds two waves whose dependent MFMA
+// chains interleave, so the matrix pipe was not waiting on the chain; the 64-row tiles only add 14 % padded rows at D = 200.
+// Dropped.)
+
 // wide particle filters: initial particles (n, du) row-major -> u0 (same layout) [+ filtering path slot 0]
 __global__ void __launch_bounds__(kBlock) k_lgwf_init(LgDev dd, const float* u0s_all) {
     const LgDev d = chain_view(dd, blockIdx.y);

@@ -250,13 +250,15 @@ class LGSweep:
         # (same results bit for bit; FBSMI_CHAIN_GROUPS=1 keeps one handle, =k asks for k groups).
         G = 1
         if _group is None:
-            # Two groups, except large wide ensembles (launches of tens of microseconds), which take four.  Four streams of
-            # SHORT dependent launches are pathological on some boxes: round 3 measured 28-31 us per step with four groups of
-            # one chain against 16 with two, for the narrow toy and for the d = 100 toy at 100 particles alike (round 2's box
-            # had run the latter 10 % faster with four); the host is not the limit (0.3 us per graph node), the queues are.
+            # Two groups, except very large wide ensembles (launches of hundreds of microseconds), which take four.  Four
+            # streams of shorter dependent launches are pathological on some boxes: round 3 measured 28-31 us per step with
+            # four groups of one chain against 16 with two, for the narrow toy and for the d = 100 toy at 100 particles alike
+            # (round 2's box had run the latter 10 % faster with four), and d = 100 at 10 000 particles anywhere between 17
+            # and 28 ms per sweep with four groups against a steady 19-21 with two; at 100 000 particles four groups won on
+            # every box (152 against 174 ms).  The host is not the limit (0.3 us per graph node); the queues are.
             wide = max(model.du, model.dv) > 16
             G = int(os.environ.get("FBSMI_CHAIN_GROUPS", "0")) or \
-                ((4 if (wide and self.C % 4 == 0 and nparticles >= 4096) else 2) if self.C >= 4 else 1)
+                ((4 if (wide and self.C % 4 == 0 and nparticles >= 32768) else 2) if self.C >= 4 else 1)
             if G < 1 or self.C % G:
                 G = 1
         if G > 1:
