@@ -174,17 +174,21 @@ def em_finish_roofline(dev):
                  A=torch.randint(0, n, (n,), device=dev, generator=g, dtype=torch.int32),
                  us_new=torch.empty((n, em.du), device=dev), lw=torch.empty(n, device=dev),
                  img=torch.empty((n, em.D), device=dev)) for _ in range(nsets)]
+    for b in sets:   # the production dtype of configs 3-5: the autocast network reads and writes bfloat16
+        b["net16"] = b["net"].to(torch.bfloat16)
+        b["img16"] = torch.empty((n, em.D), device=dev, dtype=torch.bfloat16)
     v, vp = torch.randn(em.dv, device=dev, generator=g), torch.randn(em.dv, device=dev, generator=g)
     pin = torch.randn(em.du, device=dev, generator=g)
     st = torch.cuda.current_stream().cuda_stream
 
-    def finish(b):
-        _lib.call("fbsmi_em_finish", em.ref, b["us"].data_ptr(), b["A"].data_ptr(), b["net"].data_ptr(), None, 0, 0, 1.3,
-                  2.6, 0.002, 0.0721, v.data_ptr(), vp.data_ptr(), 1, 2, n, 0, n, 5, pin.data_ptr(), b["us_new"].data_ptr(),
-                  b["lw"].data_ptr(), st)
+    def finish(b, dt16=False):
+        _lib.call("fbsmi_em_finish", em.ref, b["us"].data_ptr(), b["A"].data_ptr(), b["net16" if dt16 else "net"].data_ptr(), None,
+                  1 if dt16 else 0, 0, 1.3, 2.6, 0.002, 0.0721, v.data_ptr(), vp.data_ptr(), 1, 2, n, 0, n, 5, pin.data_ptr(),
+                  b["us_new"].data_ptr(), b["lw"].data_ptr(), st)
 
-    def concat(b):
-        _lib.call("fbsmi_em_concat", em.ref, b["us"].data_ptr(), b["A"].data_ptr(), vp.data_ptr(), n, 0, b["img"].data_ptr(), st)
+    def concat(b, dt16=False):
+        _lib.call("fbsmi_em_concat", em.ref, b["us"].data_ptr(), b["A"].data_ptr(), vp.data_ptr(), n, 1 if dt16 else 0,
+                  b["img16" if dt16 else "img"].data_ptr(), st)
 
     def timed(fn, iters=10):
         for b in sets:
@@ -200,13 +204,22 @@ def em_finish_roofline(dev):
         return e0.elapsed_time(e1) / (iters * nsets) * 1e3
 
     fus, cus = timed(finish), timed(concat)
+    fus16, cus16 = timed(lambda b: finish(b, True)), timed(lambda b: concat(b, True))
     fbytes, cbytes = n * (8 * em.du + 8 + 4 * em.D), n * (4 * em.du + 4 * em.D)
+    fbytes16, cbytes16 = n * (8 * em.du + 8 + 2 * em.D), n * (4 * em.du + 2 * em.D)
+    roof = lambda by, us: {"avg_launch_us": us, "bytes_per_launch": by, "achieved": by / us / 1e3, "frac": by / us / 1e3 / PEAK_HBM_GBS}
     return {"bound": "hbm", "kernel": "k_em_finish (fbs_amd/csrc/fbsmi_em.hip)", "shape": "config 5 per-GPU share: 2048 rows, "
             "du=3072, dv=9216, float32 network output, cold (4 buffer sets, 600 MB)", "avg_launch_us": fus,
             "bytes_per_launch": fbytes, "achieved": fbytes / fus / 1e3, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": fbytes / fus / 1e3 / PEAK_HBM_GBS, "traffic": None,
-            "concat_kernel": {"avg_launch_us": cus, "bytes_per_launch": cbytes, "achieved": cbytes / cus / 1e3,
-                              "frac": cbytes / cus / 1e3 / PEAK_HBM_GBS},
+            "concat_kernel": roof(cbytes, cus),
+            "bf16_network": {"note": "the same launches with the bfloat16 network output / input the autocast networks of configs "
+                                     "3-5 actually produce and take (2 instead of 4 bytes per network value)",
+                             "finish_kernel": roof(fbytes16, fus16), "concat_kernel": roof(cbytes16, cus16)},
+            "limiter": "vector-instruction issue: rocprofv3 (profiles/r02_em_pmc.json) counts 22.4 M wave-instructions per launch -- "
+                       "Threefry-2x32/20 + erf_inv for 6.3 M normals, the row log-densities with a correctly rounded division each -- "
+                       "i.e. 21.8 k per SIMD x ~3 clocks = 27-28 us at 2.4 GHz before any memory wait, and 45 % of the wave-cycles "
+                       "are issue stalls (SQ_WAIT_INST_ANY): 0.55 of the HBM roof (23 us for the bfloat16 shape) lies below that floor",
             "note": "the same box's torch copy_ of 100 MB cold buffers moves 5.1 TB/s = 0.64 of the 8 TB/s peak; the finish kernel's "
                     "proposal and log-density roles queue on the same memory pipeline and their times add (with the normals "
                     "pre-drawn it is no faster): see DESIGN.md section 5.0"}

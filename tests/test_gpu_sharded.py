@@ -66,6 +66,30 @@ def _worker(rank, world, port, q):
                                            sb.transition_logpdf, sb.likelihood_logpdf, sh, explicit_final=ef, mask_=mask)
                 same = all(torch.equal(a, b) for a, b in zip(got, want))
                 ok = ok and same and sh.bytes_moved > 0
+        # ---- the linear-Gaussian closures (fbsmi_lg_transition_sampler_rows: the noise a row slice of the global draw) on a
+        # sharded ensemble against the fused single-GPU sweep engine, for a narrow model and for a wide (d = 24) one
+        import fbs_amd
+        from fbs_amd.sdes import StationaryConstLinearSDE
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import toy_4d, toy_gp
+        for toy, N, T2 in ((toy_4d(), 300, 9), (toy_gp(24), 130, 5)):
+            ts2 = np.linspace(0, 1.0, T2 + 1)
+            br = fbs_amd.LinearGaussianBridge(toy["m0"], toy["cov0"], StationaryConstLinearSDE(a=-0.5, b=1.0), ts2, toy["du"], device=dev)
+            rng = np.random.default_rng(N)
+            x0l = torch.from_numpy(rng.normal(size=br.du).astype(np.float32)).to(dev)
+            y0l = torch.from_numpy(np.asarray(toy["y0"], np.float32)).to(dev)
+            bsl = rng.integers(0, N, T2 + 1).astype(np.int32)
+            keyl = ops.PRNGKey(77)
+            want = br.gibbs_kernel(keyl, x0l, y0l, bsl, N, True, False)
+            for exchange in ("all_gather", "all_to_all", "auto"):
+                sh = sharded.ParticleShards(N, dist=dist, exchange=exchange)
+                got = sharded.gibbs_kernel(keyl, x0l, y0l, None, bsl, ts2, br.fwd_sampler, br.sde, br.unpack, N,
+                                           br.transition_sampler, br.transition_logpdf, br.likelihood_logpdf, sh)
+                same = all(torch.equal(a.reshape(b.shape), b) for a, b in zip(got, want))
+                dg = sh.diagnostics                                  # (T + 1, 2): log-normaliser increment, ESS
+                okd = dg is not None and tuple(dg.shape) == (T2 + 1, 2) and bool(torch.isfinite(dg).all()) and \
+                    bool((dg[:, 1] >= 1.0 - 1e-4).all()) and bool((dg[:, 1] <= N + 1e-2).all())
+                ok = ok and same and okd
         dist.barrier()
         q.put((rank, bool(ok), ""))
     except Exception as e:  # report instead of hanging the other ranks' collectives forever

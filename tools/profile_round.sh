@@ -10,15 +10,15 @@ out=$PWD/gpurun_out
 export TMPDIR=/tmp
 python3 -c "from fbs_amd import _lib; _lib.build(); import oracle; oracle.build()"   # build before any profiler preload exists
 python3 bench.py > $out/${tag}_bench_stdout.json 2> $out/${tag}_bench_stderr.log
-LEAN="--steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan '' --image-steps 0 --sharded-steps 0"
+LEAN="--steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan '' --image-steps 0 --sharded-steps 0 --sharded-lg-steps 0"
 tail -c 600 $out/${tag}_bench_stdout.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o run -- python3 bench.py --no-cpu-baseline --no-single-chain --batch-scan "" --image-steps 0 --sharded-steps 0 > $out/${tag}_prof.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" --image-steps 0 --sharded-steps 0 > $out/${tag}_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" --image-steps 0 --sharded-steps 0 > $out/${tag}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o run -- python3 bench.py --no-cpu-baseline --no-single-chain --batch-scan "" --image-steps 0 --sharded-steps 0 --sharded-lg-steps 0 > $out/${tag}_prof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" --image-steps 0 --sharded-steps 0 --sharded-lg-steps 0 > $out/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" --image-steps 0 --sharded-steps 0 --sharded-lg-steps 0 > $out/${tag}_pmc_write.log 2>&1
 # VALU / SALU / memory instruction counts per wave (what actually bounds the step kernels once a few chains share a CU)
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $out/${tag}_pmc_valu -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" --image-steps 0 --sharded-steps 0 > $out/${tag}_pmc_valu.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $out/${tag}_pmc_valu -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" --image-steps 0 --sharded-steps 0 --sharded-lg-steps 0 > $out/${tag}_pmc_valu.log 2>&1
 # LDS bank-conflict counters on the scan kernels (and on the MFMA drift kernel of the d = 100 toy)
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d $out/${tag}_pmc_lds -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" --image-steps 0 --sharded-steps 0 > $out/${tag}_pmc_lds.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d $out/${tag}_pmc_lds -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan "" --image-steps 0 --sharded-steps 0 --sharded-lg-steps 0 > $out/${tag}_pmc_lds.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d $out/${tag}_pmc_lds_gp100 -o run -- python3 tools/bench_gp100.py 100 > $out/${tag}_pmc_lds_gp100.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_gp100 -o run -- python3 tools/bench_gp100.py 100 10000 > $out/${tag}_prof_gp100.log 2>&1
 find $out/${tag}_prof_gp100 -name "*kernel_trace.csv" -delete

@@ -123,7 +123,7 @@ def main():
     f4 = calib["4_bytes_per_lane"]["true_over_reported"] if calib and "4_bytes_per_lane" in calib else None
     traffic = {
         "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
-                   "--steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan '' --image-steps 0 --sharded-steps 0",
+                   "--steps 1 --warmup 1 --no-cpu-baseline --no-single-chain --batch-scan '' --image-steps 0 --sharded-steps 0 --sharded-lg-steps 0",
         "workload_text": cfg.get("workload"),
         "workload": {"nparticles": cfg.get("nparticles"), "nsteps": cfg.get("nsteps"), "nchains": cfg.get("nchains")},
         "chains_per_launch": bench["roofline"].get("chains_per_launch", cfg.get("nchains")),
