@@ -89,7 +89,8 @@ struct LgDev {
     int wide;                               // 16 < max(du, dv) <= 128: row-major particles u0/u1 [N][du], MFMA drift
     float* lpw;                             // [N][dv rounded up to 4] per-row log-density terms of the wide path
     int32_t* anc;                           // [N] ancestors of the current step (wide path)
-    float* xiw;                             // [N][du] the NEXT step's noise, drawn by the previous launch (one-tile wide Gibbs)
+    float* xiw;                             // [2][N][du] a step's noise, drawn ahead of the launch that uses it (wide models): slot s & 1
+                                            // for the one-tile Gibbs step (drawn DURING the previous launch), slot 0 for k_lgw_noise
     int lh_w, lh_j;                         // their depths
     // two-launch step (N a power of two, 2..256 tiles): the searches walk the summation tree itself, so no cdf is written
     float2* trW;                            // [nb][64]: per tile, heap-ordered nodes (sum of the node's left half, w at its midpoint)
@@ -160,7 +161,7 @@ __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
     if (d.lpw) {
         d.lpw += (size_t)((d.dv + 3) & ~3) * N * c;
         d.anc += N * c;
-        d.xiw += N * du * c;
+        d.xiw += 2 * N * du * c;
     }
     if (d.hpW) {
         d.hpW += (size_t)kHeapSizeW * c;
@@ -2260,9 +2261,40 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     // (log-density terms, particles, noise) is found in that XCD's L2 instead of behind the fabric.
     // (the filters' launches, whose kres is a step index, ask for it with bit 8 of `emit`: class 0)
     const bool pin = (KIND == 1 && kres >= 8) || (KIND != 1 && (emit & 0x100));
-    if (pin && (int)(blockIdx.x & 7) != (KIND == 1 ? kres - 8 : 0)) return;
+    const int pslot = KIND == 1 ? (kres - 8 + 2 * (int)blockIdx.y) & 7 : 0;   // chain y of the launch on XCD class base + 2 y
     const int bx = pin ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, gx = pin ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    if (pin && (int)(blockIdx.x & 7) != pslot) {
+        // The seven blocks out of eight that sit on the other XCDs: in the Gibbs step they draw the NEXT step's noise (into the
+        // other half of d.xiw) while the working blocks run -- it used to be the working blocks' last 1.4 us.
+        if (KIND == 1) {
+            const LgDev dq = chain_view(dd, blockIdx.y);
+            if (s + 1 < dq.T) {
+                const uint32_t n0 = dq.keytab[8 * (s + 1) + 6], n1 = dq.keytab[8 * (s + 1) + 7];
+                const int total = dq.N * dq.du;
+                const int r8 = (int)(blockIdx.x & 7), idle = bx * 7 + (r8 > pslot ? r8 - 1 : r8), nidle = gx * 7;
+                float* dst = dq.xiw + (size_t)((s + 1) & 1) * total;
+                for (int e = idle * kBlock + (int)threadIdx.x; e < total; e += nidle * kBlock)
+                    dst[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
+            }
+        }
+        return;
+    }
     const LgDev d = chain_view(dd, blockIdx.y);
+    // Unpinned one-tile Gibbs launches carry a few EXTRA blocks behind the working ones: they draw the next step's noise (into
+    // the other half of d.xiw) on CUs of their own while the step runs, instead of every working block spending its last
+    // 1.4 us on a share of it.
+    const int work = ((d.N + kWideTile - 1) / kWideTile) * nrt;   // working blocks of a launch that covers all row tiles
+    const bool extra_noise = KIND == 1 && !pin && (int)gridDim.x > work;
+    if (extra_noise && bx >= work) {
+        if (s + 1 < d.T) {
+            const uint32_t n0 = d.keytab[8 * (s + 1) + 6], n1 = d.keytab[8 * (s + 1) + 7];
+            const int total = d.N * d.du, nx = (int)gridDim.x - work;
+            float* dst = d.xiw + (size_t)((s + 1) & 1) * total;
+            for (int e = (bx - work) * kBlock + (int)threadIdx.x; e < total; e += nx * kBlock)
+                dst[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
+        }
+        return;
+    }
     __shared__ LgwPreLds pre;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* Gs = dyn;                    // [32 rows][S]: rows 32*tr .. of G_s
@@ -2353,7 +2385,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
 #pragma unroll
         for (int vv = 0; vv < 4; ++vv) {
             const int r = row0 + vv;
-            xi[vv] = (r < du && mo < N) ? d.xiw[(size_t)mo * du + r] : 0.0f;
+            xi[vv] = (r < du && mo < N) ? d.xiw[(size_t)(s & 1) * N * du + (size_t)mo * du + r] : 0.0f;
         }
     };
     if (KIND == 1 || KIND == 2) {   // the G tile is on its way; now the step's ancestors, worked out by this workgroup itself
@@ -2449,12 +2481,13 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
 #else
     const bool stamp_tail = false;
 #endif
-    if (KIND == 1 && (s + 1 < d.T || stamp_tail)) {   // this workgroup's share of the next step's noise
-        const int sn = s + 1 < d.T ? s + 1 : s;
+    if (KIND == 1 && !pin && !extra_noise && (s + 1 < d.T || stamp_tail)) {   // this workgroup's share of the next step's noise (pinned
+        const int sn = s + 1 < d.T ? s + 1 : s;               // launches: the idle blocks on the other XCDs drew it)
         const uint32_t n0 = d.keytab[8 * sn + 6], n1 = d.keytab[8 * sn + 7];
         const int total = N * du, per = (total + gx - 1) / gx;
         const int e0 = bx * per, e1 = e0 + per < total ? e0 + per : total;
-        for (int e = e0 + t; e < e1; e += kBlock) d.xiw[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
+        float* dst = d.xiw + (size_t)((s + 1) & 1) * total;   // the other half: blocks of this launch may still be reading this step's
+        for (int e = e0 + t; e < e1; e += kBlock) dst[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
     }
     FBSMI_STAMP(24)
 }
@@ -3319,6 +3352,27 @@ static bool xcd_round_robin_holds() {
     return ok != 0;
 }
 
+// Launch streams come from a process-wide pool of four, created once and never destroyed: handle (group) g of a batch uses
+// stream g % 4.  One stream per handle made the number of streams -- and with it the hardware queue a stream lands on -- depend
+// on how many handles a process had created before: with the queues oversubscribed two chain groups could end up sharing one
+// and a 16 us step took 29 (round 3: the d = 100 toy at 100 particles measured 3.0 ms per sweep alone and 5.9 ms when a
+// smaller ensemble's handles had been created first).
+constexpr int kStreamPool = 4;
+static hipStream_t pool_stream(int g) {
+    static hipStream_t pool[kStreamPool] = {nullptr, nullptr, nullptr, nullptr};
+    static int dev_of[kStreamPool] = {-1, -1, -1, -1};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int i = ((g % kStreamPool) + kStreamPool) % kStreamPool;
+    if (!pool[i] || dev_of[i] != dev) {   // (one device per process is the rule: one rank per GPU; a second device gets fresh streams)
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        pool[i] = st;
+        dev_of[i] = dev;
+    }
+    return pool[i];
+}
+
 struct fbsmi_lg_sweep {
     LgDev d{};
     int items = 1, dmax = 2;
@@ -3455,9 +3509,17 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
         ProfScope p(s, 2, st);
         if (d.wide) {
             static const int pin = [] { const char* e = getenv("FBSMI_WIDE_PIN"); return (e ? atoi(e) : 1) && xcd_round_robin_holds(); }();
+            // (one chain per launch only: with two chains per launch and two chain groups in flight the pinned step measured
+            // 29 us against 16 unpinned, round 3)
             if (pin && d.C == 1 && gwide.x <= 32)
-                k_lgw_gemm<1><<<dim3(gwide.x * 8, 1), kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 8 + ((2 * d.c0) & 7));
-            else k_lgw_gemm<1><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
+                k_lgw_gemm<1><<<dim3(gwide.x * 8, d.C), kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 8 + ((2 * d.c0) & 7));
+            else {
+                // (+ extra blocks that draw the next step's noise beside the step: one per 1024 elements, at most 16)
+                const int64_t tot = (int64_t)d.N * d.du;
+                static const int extra_on = [] { const char* e = getenv("FBSMI_WIDE_EXTRA"); return e ? atoi(e) : 1; }();
+                const int extra = !extra_on ? 0 : (int)((tot + 1023) / 1024 < 16 ? (tot + 1023) / 1024 : 16);
+                k_lgw_gemm<1><<<dim3(gwide.x + extra, d.C), kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
+            }
         }
         else LG_DISPATCH(s, (void)ITEMS; (k_lg_step1<DMAX><<<gone, kBlock, 0, st>>>(d, k)));
     }
@@ -3684,7 +3746,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     if (wide) {
         rc |= slab_request(s, &d.lpw, C * (size_t)((d.dv + 3) & ~3) * N);
         rc |= slab_request(s, &d.anc, C * N);
-        rc |= slab_request(s, &d.xiw, C * N * d.du);
+        rc |= slab_request(s, &d.xiw, 2 * C * N * d.du);
     }
     d.hpW = d.hpJ = nullptr;
     d.hp_map = nullptr;
@@ -3754,7 +3816,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         return FBSMI_ERR_HIP;
     }
     (void)xcd_round_robin_holds();   // the once-per-process placement probe must not run inside a later stream capture
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+    if ((s->stream = pool_stream(0)) == nullptr ||
         hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming) != hipSuccess) {
         fbsmi_lg_sweep_destroy(s);
@@ -3789,7 +3851,7 @@ void fbsmi_lg_sweep_destroy(fbsmi_lg_sweep* s) {
         for (auto e : s->prof_ev[w]) hipEventDestroy(e);
     if (s->ev_in) hipEventDestroy(s->ev_in);
     if (s->ev_out) hipEventDestroy(s->ev_out);
-    if (s->stream) hipStreamDestroy(s->stream);
+    // (the stream belongs to the pool)
     for (void* p : s->allocs) hipFree(p);
     delete s;
 }
@@ -3874,6 +3936,7 @@ int fbsmi_lg_sweep_set_group(fbsmi_lg_sweep* s, int32_t nchains_total, int32_t f
     if (s->graph_chain) return fail(FBSMI_ERR_ARG, "lg_sweep_set_group: call it before the handle's first chain sweep");
     s->d.Ctot = nchains_total;
     s->d.c0 = first_chain;
+    if (hipStream_t st = pool_stream(first_chain / s->d.C)) s->stream = st;   // group g of the batch: pool stream g
     return FBSMI_OK;
 }
 
