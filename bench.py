@@ -464,6 +464,14 @@ def main():
                     if "cdf" not in kern else "k_lg_prop (resample + gather + Euler-Maruyama + log-weight)",
                     "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                     "traffic": None, "from_profile_file": prof,
+                    # the roof that does bind once a few chains share a CU, as its own fraction (rocprofv3 instruction counts of a
+                    # separate run of this command x measured issue cycles, against this run's launch time)
+                    "valu_roof": ({"bound": "vector-instruction issue", "unit": "wave-instructions/s",
+                                   "achieved": prof["valu_insts_per_launch"] / (prop_us * 1e-6),
+                                   "peak": 1024 * 2.4e9 / 2.7, "frac": prof["valu_issue_frac"],
+                                   "note": "1024 SIMDs x 2.4 GHz / 2.7 measured issue cycles per instruction of this mix; one "
+                                           "launch running alone (two are in flight during the timed sweeps)"}
+                                  if prof and prof.get("valu_issue_frac") is not None else None),
                     "limiter": "vector-instruction issue and dependent round trips (the per-step working set is cache resident): "
                                "the HBM fraction is reported because SURVEY 8(d) assigns this path the HBM roof, not because "
                                "the kernel is near it",

@@ -68,8 +68,25 @@ def _lg_model_of(*closures):
 
 
 def _same_sde(a, b) -> bool:
-    """The same SDE object, or one of the same class with the same coefficients."""
-    return a is b or (type(a) is type(b) and vars(a) == vars(b))
+    """The same SDE object, or one of the same class with the same coefficients (scalars or arrays)."""
+    if a is b:
+        return True
+    if type(a) is not type(b):
+        return False
+    va, vb = vars(a), vars(b)
+    if va.keys() != vb.keys():
+        return False
+    for k in va:
+        x, y = va[k], vb[k]
+        if isinstance(x, torch.Tensor) or isinstance(y, torch.Tensor):
+            x = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x
+            y = y.detach().cpu().numpy() if isinstance(y, torch.Tensor) else y
+        try:
+            if not np.array_equal(np.asarray(x), np.asarray(y)):
+                return False
+        except Exception:
+            return False
+    return True
 
 
 def gibbs_kernel(key, x0, y0, us_star, bs_star, ts, fwd_sampler, sde, unpack, nparticles, transition_sampler,
@@ -80,7 +97,8 @@ def gibbs_kernel(key, x0, y0, us_star, bs_star, ts, fwd_sampler, sde, unpack, np
     Returns (x0, us_star, bs_star, acc) like the reference."""
     # the fused engine runs the model's OWN grid, SDE and split: take it only when the caller passed exactly those
     model = _lg_model_of(fwd_sampler, transition_sampler, likelihood_logpdf, unpack)
-    if model is not None and not marg_y and not kwargs and _same_sde(sde, model.sde) and model.same_grid(ts) and \
+    # (with marg_y=False the reference never touches `sde` (gibbs.py:130) and its drivers may pass None, experiments/sb/gibbs.py:171)
+    if model is not None and not marg_y and not kwargs and (sde is None or _same_sde(sde, model.sde)) and model.same_grid(ts) and \
             (explicit_backward or _lg_model_of(transition_logpdf) is model) and \
             model.fused_sweep_supported(nparticles, explicit_final):
         with torch.cuda.device(model.device):

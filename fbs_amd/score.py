@@ -264,8 +264,17 @@ class ScoreBridge:
 
 
 def bridge_of(*closures):
-    """The ScoreBridge all the given closures are bound methods of, or None."""
+    """The ScoreBridge whose OWN transition_sampler / likelihood_logpdf (in that order; a third closure, if given, its
+    transition_logpdf) the given closures are, or None.  Callers replace the pair by ``fused_step``, which has exactly those two
+    methods' semantics -- so a subclass override, another method of the bridge (e.g. transition_logpdf passed as the weight
+    function) or a swapped pair must not be taken for them."""
     owners = [getattr(c, "__self__", None) for c in closures]
-    if not owners or not isinstance(owners[0], ScoreBridge):
+    if not owners or not isinstance(owners[0], ScoreBridge) or not all(o is owners[0] for o in owners):
         return None
-    return owners[0] if all(o is owners[0] for o in owners) else None
+    want = (ScoreBridge.transition_sampler, ScoreBridge.likelihood_logpdf, ScoreBridge.transition_logpdf)
+    if len(closures) > len(want):
+        return None
+    for c, w in zip(closures, want):
+        if getattr(c, "__func__", None) is not w:
+            return None
+    return owners[0]

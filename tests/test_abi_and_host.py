@@ -157,3 +157,34 @@ def test_nn_kernels_refuse_unsupported_shapes_loudly():
         _lib.call("fbsmi_nn_bias_add", p, 1, 10, 12, p, None)                         # C not a multiple of 8
     with pytest.raises(RuntimeError):
         _lib.call("fbsmi_nn_pixel_shuffle", p, p, 1, 2, 7, 7, 4, 2, None, None)       # c not a multiple of 8
+
+
+def test_bridge_of_recognises_only_the_bridges_own_pair():
+    """the fused score-network step replaces (transition_sampler, likelihood_logpdf); another method of the same
+    bridge, a swapped pair or a subclass override must not be mistaken for them."""
+    from fbs_amd.score import ScoreBridge, bridge_of
+    sb = object.__new__(ScoreBridge)
+    assert bridge_of(sb.transition_sampler, sb.likelihood_logpdf) is sb
+    assert bridge_of(sb.transition_sampler, sb.likelihood_logpdf, sb.transition_logpdf) is sb
+    assert bridge_of(sb.transition_sampler, sb.transition_logpdf) is None          # the wrong weight function
+    assert bridge_of(sb.likelihood_logpdf, sb.transition_sampler) is None          # swapped
+    assert bridge_of(sb.transition_sampler, object.__new__(ScoreBridge).likelihood_logpdf) is None   # two bridges
+
+    class Mine(ScoreBridge):
+        def likelihood_logpdf(self, *a, **k):
+            return None
+    m = object.__new__(Mine)
+    assert bridge_of(m.transition_sampler, m.likelihood_logpdf) is None            # an override is not the built-in
+    assert bridge_of(lambda *a: None, lambda *a: None) is None
+
+
+def test_same_sde_compares_coefficients_of_any_kind():
+    from fbs_amd.samplers.gibbs import _same_sde
+    from fbs_amd.sdes import StationaryConstLinearSDE, StationaryLinLinearSDE
+    a, b = StationaryConstLinearSDE(a=-0.5, b=1.0), StationaryConstLinearSDE(a=-0.5, b=1.0)
+    assert _same_sde(a, a) and _same_sde(a, b) and not _same_sde(a, StationaryConstLinearSDE(a=-0.4, b=1.0))
+    assert not _same_sde(a, StationaryLinLinearSDE(0.02, 5.0, 0.0, 2.0))
+    a.extra, b.extra = np.arange(3.0), np.arange(3.0)          # array attributes no longer raise
+    assert _same_sde(a, b)
+    b.extra = np.arange(4.0)
+    assert not _same_sde(a, b)
