@@ -50,6 +50,8 @@ constexpr int kNumProfKernels = 3; // norm, cdf, prop
 struct LgDev {
     int C;           // independent chains batched in every launch (blockIdx.y): jax.vmap over chains
     int Ctot, c0;    // this handle drives chains c0 .. c0 + C - 1 of a batch of Ctot (fbsmi_lg_sweep_set_group; default C, 0)
+    int plus1;       // N = 2^k + 1 (explicit_final on a power-of-two ensemble): the two-launch step over the first 2^k slots'
+                     // summation tree plus one extra tile that holds the last slot (see tree_build)
     int pin;         // small ensembles: the two-launch step's grids are 8x as wide and only every eighth block works, so the
                      // whole step runs on ONE XCD (blocks b and b + 8 share one) and its hand-offs stay in that XCD's L2
     int N;           // rows of the particle system (nparticles, +1 when explicit_final)
@@ -555,7 +557,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
         if (in) {
             const float w = fbsmi_expf(l[i]);
             xw[i] = w;
-            if (MODE == 0) xj[i] = e == i_ref ? 0.0f : (PUB ? jprob_pow2(w, w_max, inv_n) : jprob_at(w, w_max, d.N));
+            if (MODE == 0) xj[i] = e == i_ref ? 0.0f : ((PUB && !d.plus1) ? jprob_pow2(w, w_max, inv_n) : jprob_at(w, w_max, d.N));
             if (MODE == 1) xj[i] = fm_rest_at(w, w_k, e == i_ref, d.N);
         }
         // several elements per thread: left alone, the scheduler interleaves all sixteen float64 exponentials and their
@@ -1314,16 +1316,19 @@ __device__ __forceinline__ int tree_walk_n(const float2* heap, int h, int levels
 struct TreeEntry {
     float sw, sj, wf;       // tile `tid`: sum of w, sum of J_prob ([i*] = 0), w of its first element
     float refsib[8];        // sibling sums of the leaf i* in its tile's J_prob tree (published by k_lg_norm)
+    float xw, xj;           // N = 2^k + 1: w and J_prob ([i*] = 0) of the last slot (the extra tile's sums); else 0
     float4 stg[kMidN / 2];  // this thread's part of trWtop
 };
 
 __device__ __forceinline__ TreeEntry tree_entry_loads(const LgDev& d, int i_ref) {
-    const int tid = threadIdx.x, nb = d.nb;
+    const int tid = threadIdx.x, nb = d.nb - d.plus1;   // tiles of the power-of-two part
     TreeEntry e;
     const bool tl = tid < nb;
     e.sw = tl ? d.bsumw[tid] : 0.0f;
     e.sj = tl ? d.bsumJ[tid] : 0.0f;
     e.wf = tl ? d.wfirst[tid] : 0.0f;
+    e.xw = d.plus1 ? d.bsumw[nb] : 0.0f;
+    e.xj = d.plus1 ? d.bsumJ[nb] : 0.0f;
 #pragma unroll
     for (int lv = 0; lv < 8; ++lv) e.refsib[lv] = d.scal[4 + lv];
 #pragma unroll
@@ -1346,11 +1351,20 @@ struct TreeLds {
 constexpr int kTreeBuildBarriers = 4;   // __syncthreads() executed by tree_build (two up-sweep exchanges, two explicit)
 
 // Builds the heaps and finds J = choice(key_3, N, (), p=J_prob) (resamplings.py:84), the same in every thread;
-// `last` = cdf[N - 1].  Ends with every heap visible to the workgroup.
+// `last` = cdf[N - 1], `rootW` = the canonical inclusive prefix at the end of the power-of-two part (== last unless N = 2^k + 1).
+// Ends with every heap visible to the workgroup.
+//
+// N = 2^k + 1 (LgDev.plus1).  The fixed-length bisection over 2^k + 1 elements probes, level by level, exactly the midpoints
+// of the 2^k-leaf tree's nodes: an interval [a, a + 2^j + 1) on the right spine has its midpoint at a + 2^(j-1), the midpoint
+// of the tree node [a, a + 2^j), and every left turn enters an aligned power-of-two block with the same number of levels left
+// as in the 2^k walk.  The two walks differ only at the end of the all-right path, where the last level compares with
+// cdf[2^k] = the total, which every query is below -- and both return 2^k there.  So the searches run over the tree of the
+// first 2^k slots with queries scaled by the whole total; the last slot is an extra tile of one element that joins the sums.
 __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, TreeLds& L, int i_ref, float u3, float w_max,
-                                          float inv_n, float& last) {
-    const int nb = d.nb, tid = threadIdx.x;
-    const int b_ref = i_ref / kBlock;
+                                          float inv_n, float& last, float& rootW) {
+    const int nb = d.nb - d.plus1, tid = threadIdx.x;
+    const bool ref_extra = d.plus1 && i_ref == d.N - 1;   // the reference index is the last slot: nothing changes in the tree
+    const int b_ref = ref_extra ? 0 : i_ref / kBlock;
 #pragma unroll
     for (int k = 0; k < kMidN / 2; ++k) {
         const int idx = tid + kBlock * k;
@@ -1378,8 +1392,9 @@ __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, Tr
         t2[0] = waves_combine(L.xch[0][0], L.xch[0][1], L.xch[0][2], L.xch[0][3], s2[0], p2[0]);
         t2[1] = waves_combine(L.xch[1][0], L.xch[1][1], L.xch[1][2], L.xch[1][3], s2[1], p2[1]);
     }
-    last = t2[0];                                  // == cdf[N - 1]
-    const float Ji = fmaxf(1.0f - t2[1], 0.0f);    // J_prob[i*] (resamplings.py:80-82)
+    rootW = t2[0];
+    last = d.plus1 ? t2[0] + e.xw : t2[0];         // == cdf[N - 1] (the padded tree's root: left half + the last slot)
+    const float Ji = fmaxf(1.0f - (d.plus1 ? t2[1] + e.xj : t2[1]), 0.0f);    // J_prob[i*] (resamplings.py:80-82)
     if (tid) L.topW[g] = make_float2(tree_left_sum(p2[0], tid), e.wf);
     // the tile that holds i*: its leaf changes from 0 to Ji, so the tile's sum is redone along the leaf's path ...
     const float tile_ref = tree_fold(Ji, e.refsib);
@@ -1392,14 +1407,17 @@ __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, Tr
         bsib[6] = L.xch[1][wb ^ 1];
         bsib[7] = (wb & 2) ? L.xch[1][0] + L.xch[1][1] : L.xch[1][2] + L.xch[1][3];
     }
-    const float lastJ = tree_fold(tile_ref, bsib);   // == cdfJ[N - 1]
+    // the root of the power-of-two part's J_prob tree, and cdfJ[N - 1]
+    const float rootJ = ref_extra ? t2[1] : tree_fold(tile_ref, bsib);
+    const float lastJ = d.plus1 ? rootJ + (ref_extra ? Ji : e.xj) : rootJ;
     if (tid) {
         // node g: leaves [tid - 2^c, tid + 2^c), c = ctz(tid); its left half holds b_ref iff tid - 2^c <= b_ref < tid, and then
         // the half's sum is the fold of the new leaf over the first c levels of that path
         const int c = __builtin_ctz(tid);
-        const bool hit = b_ref < tid && b_ref >= tid - (1 << c);
+        const bool hit = !ref_extra && b_ref < tid && b_ref >= tid - (1 << c);
         const float left = hit ? tree_fold(tile_ref, bsib, c) : tree_left_sum(p2[1], tid);
-        const float jf = tid * kBlock == i_ref ? Ji : (tid < nb ? jprob_pow2(e.wf, w_max, inv_n) : 0.0f);
+        const float jw = d.plus1 ? jprob_at(e.wf, w_max, d.N) : jprob_pow2(e.wf, w_max, inv_n);
+        const float jf = tid * kBlock == i_ref ? Ji : (tid < nb ? jw : 0.0f);
         L.topJ[g] = make_float2(left, jf);
     }
     __syncthreads();
@@ -1407,13 +1425,13 @@ __device__ __forceinline__ int tree_build(const LgDev& d, const TreeEntry& e, Tr
     // walk only keeps the heap index.
     const float q = lastJ * (1.0f - u3);
     const int top_levels = 31 - __builtin_clz(nb);
-    float P = 0.0f, E = lastJ;
+    float P = 0.0f, E = rootJ;
     int h = tree_walk_n(L.topJ, kBlock / nb, top_levels, q, P, E);
     const int lo0 = (h - kBlock) * kBlock;   // first slot of the tile the walk arrived at
     const float wj = d.w[lo0 + tid];
     float s1[1], t1s[1];
     TreePath p1[1];
-    s1[0] = lo0 + tid == i_ref ? Ji : jprob_pow2(wj, w_max, inv_n);
+    s1[0] = lo0 + tid == i_ref ? Ji : (d.plus1 ? jprob_at(wj, w_max, d.N) : jprob_pow2(wj, w_max, inv_n));
     const float xj = s1[0];
     block_upsweep_n<1>(s1, p1, L.xch[4], t1s);
     if (tid) L.tileJ[g] = make_float2(tree_left_sum(p1[0], tid), xj);
@@ -1504,7 +1522,8 @@ __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) 
     const uint32_t* kt = d.keytab + 8 * s;
     const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3], t0 = kt[6], t1 = kt[7];
     const int i_ref = d.bs[s], j_ref = d.bs[s + 1];
-    const int m = tileb * kBlock + tid;   // N is a multiple of the tile: every slot is live
+    const int m = tileb * kBlock + tid;   // N is a multiple of the tile: every slot is live -- but for N = 2^k + 1, whose last
+    const bool live = m < N;              // workgroup holds one slot (LgDev.plus1; HALVES == 1 then)
     const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
     float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
     // ---- round 0: everything addressable now
@@ -1522,15 +1541,16 @@ __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) 
     const float u3 = __uint_as_float(kt[4]);
     float xi[DMAX];
 #pragma unroll
-    for (int r = 0; r < DMAX; ++r) xi[r] = r < d.du ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)m * d.du + r) : 0.0f;
+    for (int r = 0; r < DMAX; ++r)
+        xi[r] = r < d.du ? normal_at(t0, t1, (uint64_t)N * d.du, (uint64_t)(live ? m : 0) * d.du + r) : 0.0f;
     FBSMI_STAMP(7)
-    float last;
+    float last, rootW;
     int J;
     if (HALVES == 1) {
-        J = tree_build(d, te, L, i_ref, u3, w_max, inv_n, last);
+        J = tree_build(d, te, L, i_ref, u3, w_max, inv_n, last, rootW);
     } else {
         if (half == 0) {
-            J = tree_build(d, te, L, i_ref, u3, w_max, inv_n, last);
+            J = tree_build(d, te, L, i_ref, u3, w_max, inv_n, last, rootW);
             if (tid == 0) {
                 Jsh = J;
                 lastsh = last;
@@ -1542,11 +1562,13 @@ __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) 
         __syncthreads();
         J = Jsh;
         last = lastsh;
+        rootW = last;    // (several tiles per workgroup: powers of two only)
     }
     int shift = (j_ref - J) % N;   // roll by j - J (:85)
     if (shift < 0) shift += N;
     int src = m - shift;
     if (src < 0) src += N;
+    if (!live) src = 0;
     FBSMI_STAMP(9)
     // ---- round 2
     const float ws = d.w[src];
@@ -1556,10 +1578,10 @@ __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) 
     const float u1 = uniform_at(a0, a1, (uint64_t)N, (uint64_t)src);
     const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)src);
     const float qK[1] = {last * (1.0f - u2)};                               // resamplings.py:73-74
-    float P[1] = {0.0f}, E[1] = {last};
+    float P[1] = {0.0f}, E[1] = {rootW};
     int tile[1], h[1], hi[1] = {0};
-    tree_search_lds(L, d.nb, qK[0], P[0], E[0], tile[0], h[0]);
-    const bool killed[1] = {u1 * w_max >= ws};                              // :71
+    tree_search_lds(L, d.nb - d.plus1, qK[0], P[0], E[0], tile[0], h[0]);
+    const bool killed[1] = {live && u1 * w_max >= ws};                      // :71
     FBSMI_STAMP(10)
     // ---- rounds 3, 4 (killed slots only)
     // The ancestor is one of the last four leaves or the slot behind them: for narrow states its row is fetched together
@@ -1604,7 +1626,7 @@ __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) 
         for (int r = 0; r < DMAX; ++r) u[r] = uref[r];
     }
     float lv[1];
-    if (d.As) d.As[(size_t)s * N + m] = a;
+    if (d.As && live) d.As[(size_t)s * N + m] = a;
     // transition_sampler (gp_gibbs.py:120-122) and the pin of csmc.py:143
 #pragma unroll
     for (int r = 0; r < DMAX; ++r) {
@@ -1612,12 +1634,14 @@ __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) 
             const float dr = drift_row<DMAX>(t, r, u, v_prev);
             float x = (u[r] + dr * t.dt) + t.sd * xi[r];
             if (pinned) x = ustar[r];
-            un[(size_t)r * N + m] = x;
-            if (d.uss) d.uss[((size_t)(s + 1) * N + m) * d.du + r] = x;
+            if (live) {
+                un[(size_t)r * N + m] = x;
+                if (d.uss) d.uss[((size_t)(s + 1) * N + m) * d.du + r] = x;
+            }
         }
     }
-    const float l = lg_loglik<DMAX>(t, u, v, v_prev);   // likelihood_logpdf on the gathered particle (csmc.py:145)
-    d.lw[m] = l;
+    const float l = live ? lg_loglik<DMAX>(t, u, v, v_prev) : -__builtin_inff();   // likelihood_logpdf on the gathered particle (csmc.py:145)
+    if (live) d.lw[m] = l;
     lv[0] = l;
     FBSMI_STAMP(12)
     float mx, sx;
@@ -1680,7 +1704,8 @@ __global__ void __launch_bounds__(kBlock) k_lg_prop2t(LgDev dd, int s) {
         }
     }
     float last;
-    const int J = tree_build(d, te, L, i_ref, u3, w_max, inv_n, last);
+    float rootW_unused;
+    const int J = tree_build(d, te, L, i_ref, u3, w_max, inv_n, last, rootW_unused);
     int shift = (j_ref - J) % N;
     if (shift < 0) shift += N;
     int src[2];
@@ -3556,13 +3581,13 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                 else
                     k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
                 k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
-            } else if (tree && two_slot) {
+            } else if (tree && two_slot && !d.plus1) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2t<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
-            } else if (tree && nb % 4 == 0 && (s->tree_halves == 4 || (s->tree_halves < 0 && (int64_t)nb * d.C >= 4 * 256))) {
+            } else if (tree && !d.plus1 && nb % 4 == 0 && (s->tree_halves == 4 || (s->tree_halves < 0 && (int64_t)nb * d.C >= 4 * 256))) {
                 // four tiles per 1024-thread workgroup once there are four tiles per CU (measured 8.57 against 8.80 ms per
                 // 4-chain sweep with two; a single chain is fastest with one tile per workgroup)
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1t<DMAX, 4><<<dim3(nb / 4, d.C), 4 * kBlock, 0, st>>>(d, k)));
-            } else if (tree && (s->tree_halves == 2 || (s->tree_halves < 0 && (int64_t)nb * d.C >= 2 * 256))) {
+            } else if (tree && !d.plus1 && nb % 2 == 0 && (s->tree_halves == 2 || (s->tree_halves < 0 && (int64_t)nb * d.C >= 2 * 256))) {
                 // two adjacent tiles per 512-thread workgroup: half the waves skip the tree building (measured +2 % at 4 chains,
                 // -1 % for a single chain, which keeps one tile per workgroup)
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop1t<DMAX, 2><<<dim3(nb / 2, d.C), 2 * kBlock, 0, st>>>(d, k)));
@@ -3763,7 +3788,14 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     }
     d.trW = d.trWtop = nullptr;
     d.wfirst = nullptr;
-    if (s->items == 1 && !wide && (d.N & (d.N - 1)) == 0 && d.nb >= 2 && d.nb <= kBlock) {
+    const bool pow2 = (d.N & (d.N - 1)) == 0 && d.nb >= 2 && d.nb <= kBlock;
+    // N = 2^k + 1 (explicit_final on a power-of-two ensemble): the same step over the first 2^k slots' tree plus an extra
+    // one-slot tile (tree_build)
+    const bool pow2p1 = d.N > 2 && ((d.N - 1) & (d.N - 2)) == 0 && d.nb - 1 >= 2 && d.nb - 1 <= kBlock &&
+                        !(getenv("FBSMI_TREE_PLUS1") && atoi(getenv("FBSMI_TREE_PLUS1")) == 0);
+    d.plus1 = 0;
+    if (s->items == 1 && !wide && (pow2 || pow2p1)) {
+        d.plus1 = pow2 ? 0 : 1;
         rc |= slab_request(s, &d.trW, C * (size_t)kTreeNodes * d.nb);
         rc |= slab_request(s, &d.trWtop, C * (size_t)kMidN * d.nb);
         rc |= slab_request(s, &d.wfirst, C * (size_t)d.nb);
@@ -3772,7 +3804,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         const char* pe = getenv("FBSMI_PIN");
         const char* pm = getenv("FBSMI_PIN_MAX");   // (diagnostic: workgroups per launch up to which the step is pinned)
         const int64_t pin_max = pm ? atoi(pm) : 64;   // two workgroups per CU of the XCD: measured better up to there, worse beyond
-        d.pin = (s->tree_step && !s->generic_prop && s->tree_halves < 0 && s->two_slot_prop < 0 && (int64_t)d.nb * C <= pin_max &&
+        d.pin = (!d.plus1 && s->tree_step && !s->generic_prop && s->tree_halves < 0 && s->two_slot_prop < 0 && (int64_t)d.nb * C <= pin_max &&
                  (int64_t)d.nb * C < 2 * 256 && !(pe && atoi(pe) == 0)) ? 1 : 0;
         if (d.pin && !xcd_round_robin_holds()) d.pin = 0;   // the dispatch order the pinning rests on is not what this machine does
     }
@@ -4085,7 +4117,7 @@ int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
     }
     LG_DISPATCH(s, (k_filt_init<ITEMS, DMAX><<<gtile, kBlock, 0, st>>>(d, f->u0s)));
     // N a power of two with 2..256 tiles: the searches walk the summation tree, a step is two launches (no cdf)
-    const bool tree = s->tree_step && d.trW && s->items == 1;
+    const bool tree = s->tree_step && d.trW && s->items == 1 && !d.plus1;
     if (tree) {
         const dim3 gpin(gtile.x * (d.pin ? 8 : 1), d.C);   // (pinned to one XCD when the launches are small: LgDev.pin)
         for (int k = 0; k < d.T; ++k) {

@@ -83,6 +83,10 @@ CASES = [
     (toy_31, 2048, 8, 1.0, False, False),     # ... with the stored path
     (toy_2d, 4095, 8, 1.0, True, True),       # ... explicit_final: N + 1 = 4096 slots
     (toy_2d, 32768, 6, 1.0, True, False),
+    (toy_4d, 512, 9, 1.0, True, True),        # explicit_final on a power of two: N + 1 = 2^k + 1 slots, still two launches
+    (toy_2d, 4096, 8, 1.0, True, True),       # ... (the tree of the first 2^k slots + an extra one-slot tile)
+    (toy_31, 1024, 6, 1.0, False, True),      # ... with the stored path
+    (toy_2d, 65536, 4, 1.0, True, True),      # ... BASELINE config 2's ensemble with explicit_final: 65 537 slots
 ]
 
 
@@ -411,6 +415,35 @@ def test_tree_step_reference_indices_on_tile_edges(tree, oracle, dev, monkeypatc
         _eq(_np(v["lw_T"]), want[5], "final log-weights")
         for i, what in enumerate(("x0_next", "us_star_next", "bs_star_next", "acc")):
             _eq(_np(got[i]), want[i], what)
+
+
+@pytest.mark.parametrize("plus1", ["1", "0"])
+def test_power_of_two_plus_one_slots_with_the_reference_on_the_last_slot(plus1, oracle, dev, monkeypatch):
+    """N = 2^k + 1 rows (explicit_final): the two-launch step walks the tree of the first 2^k slots, the last slot is an extra
+    tile.  Reference indices on the last slot itself (its J_prob leaf is the one that changes), on tile edges, and several
+    chains; FBSMI_TREE_PLUS1=0 keeps the three-launch step for comparison."""
+    monkeypatch.setenv("FBSMI_TREE_PLUS1", plus1)
+    toy = toy_2d()
+    n, T, C = 2048, 10, 3
+    N = n + 1
+    ts = np.linspace(0, 1.0, T + 1)
+    br = _bridge(toy, ts, dev)
+    om = oracle_model_from(oracle, br)
+    rng = np.random.default_rng(17)
+    x0 = rng.normal(size=(C, br.du)).astype(np.float32)
+    bs = rng.integers(0, N, (C, T + 1)).astype(np.int32)
+    bs[0] = [N - 1, 0, N - 1, N - 1, 255, 256, N - 2, N - 1, 1024, 0, N - 1]
+    keys = oracle.split(oracle.PRNGKey(29), C)
+    sweep = br.sweep_handle(n, True, True, nchains=C)
+    got = sweep.sweep(keys, x0, toy["y0"], bs)
+    v = sweep.views()
+    for c in range(C):
+        want = oracle.gibbs_kernel_lg(om, keys[c], x0[c], toy["y0"], bs[c], n, True, True, debug=True)
+        for i, what in enumerate(("x0_next", "us_star_next", "bs_star_next", "acc")):
+            _eq(_np(got[i][c]), want[i], f"{what} chain {c}")
+        _eq(_np(v["us_T"][c]), want[4], f"particles chain {c}")
+        _eq(_np(v["lw_T"][c]), want[5], f"log-weights chain {c}")
+    br._sweeps.clear()
 
 
 @pytest.mark.parametrize("tiles,toy,N,T,C", [("2", toy_4d, 4096, 6, 2), ("4", toy_31, 8192, 5, 3), ("", toy_2d, 65536, 3, 4)])
