@@ -555,6 +555,34 @@ def test_toy_twisted_driver(tmp_path, dev):
     assert set(np.load(os.path.join(str(tmp_path), "twisted-const-64-666.npz")).files) == {"samples", "gp_mean", "gp_cov"}
 
 
+def test_toy_csgm_driver(tmp_path, dev):
+    """examples/toy_csgm.py (counterpart of experiments/toy/gp_csgm.py, the `csgm` column of the paper's Table 1): the exact
+    conditional score integrated by euler_maruyama; the affine drift written out here must be the gradient the reference takes
+    by jax.grad -- checked against torch.autograd on the reference's own cond_logpdf --, the samples sit on the GP posterior,
+    the .npz schema is the reference's."""
+    import os
+    mod = _load_example("toy_csgm")
+    samples, gp_mean, gp_cov = mod.main(["--d", "6", "--nsamples", "60", "--outdir", str(tmp_path), "--quiet"])
+    assert samples.shape == (60, 6) and np.isfinite(samples).all()
+    z = (samples.mean(0) - gp_mean) / np.sqrt(np.diag(gp_cov) / 60)
+    assert np.abs(z).max() < 4.5, z
+    assert set(np.load(os.path.join(str(tmp_path), "csgm-const-666.npz")).files) == {"samples", "gp_mean", "gp_cov"}
+    # the written-out gradient against autograd of gp_csgm.py:87-92's log-density (float64, CPU)
+    d, F, Q = 4, 0.8, 0.36
+    rng = np.random.default_rng(1)
+    zs = np.linspace(0., 5., d)
+    cov = torch.tensor(np.exp(-np.abs(zs[None, :] - zs[:, None])))
+    y0 = torch.tensor(rng.normal(size=d))
+    Sx_inv = torch.linalg.inv(F ** 2 * cov + Q * torch.eye(d, dtype=torch.float64))
+    M = F * cov @ Sx_inv
+    cond_cov = cov + torch.eye(d, dtype=torch.float64) - M @ (F * cov)
+    u = torch.tensor(rng.normal(size=d), requires_grad=True)
+    lp = torch.distributions.MultivariateNormal(M @ u, covariance_matrix=cond_cov).log_prob(y0)
+    want = torch.autograd.grad(lp, u)[0]
+    got = M.T @ torch.linalg.inv(cond_cov) @ (y0 - M @ u.detach())
+    assert torch.allclose(got, want, rtol=1e-9, atol=1e-10)
+
+
 @pytest.mark.parametrize("du,dv,N,T,eb", [(24, 24, 40, 6, True), (33, 17, 255, 4, False), (20, 20, 300, 5, True)])
 def test_wide_fused_sweep_explicit_final(du, dv, N, T, eb, oracle, dev):
     """explicit_final=True on the matrix-core path: N + 1 slots, N(0, I) initial particles, initial weights from a
