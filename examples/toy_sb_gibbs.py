@@ -21,17 +21,20 @@ from fbs_amd.samplers.smc import bootstrap_backward_smoother  # noqa: E402
 from fbs_amd.sdes import euler_maruyama, make_gaussian_bw_sb  # noqa: E402
 
 
-def main(argv=None):
-    parser = argparse.ArgumentParser()
+def common_args(parser):
     parser.add_argument('--d', type=int, default=10, help='The problem dimension.')
     parser.add_argument('--nparticles', type=int, default=10, help='The number of particles.')
     parser.add_argument('--nsamples', type=int, default=1000, help='The number of samples to draw.')
-    parser.add_argument('--explicit_backward', action='store_true', default=False)
     parser.add_argument('--id', type=int, default=666, help='The id of independent MC experiment.')
     parser.add_argument('--outdir', type=str, default='./sb/results')
     parser.add_argument('--quiet', action='store_true')
-    args = parser.parse_args(argv)
-    dev = torch.device('cuda:0')
+    return parser
+
+
+def sb_setting(args, dev):
+    """The shared setting of experiments/sb/gibbs.py and experiments/sb/filter.py (:27-139 of either): GP prior, the random
+    Gaussian reference, the closed-form Gaussian Schrodinger bridge and the model closures on it.  -> namespace."""
+    from types import SimpleNamespace
     key = ops.PRNGKey(args.id)
 
     # GP setting, sb/gibbs.py:27-60
@@ -119,6 +122,26 @@ def main(argv=None):
 
     def unpack(xy):
         return xy[..., :d], xy[..., d:]
+
+    def gp_posterior_sampler(key_):                                                 # sb/filter.py:56-57
+        chol = torch.as_tensor(np.linalg.cholesky(gp_cov), dtype=torch.float32, device=dev)
+        return torch.as_tensor(gp_mean, dtype=torch.float32, device=dev) + ops.normal(key_, (d,), device=dev) @ chol   # (z @ L, as the reference writes it)
+
+    return SimpleNamespace(key=key, d=d, y0=y0, ts=ts, nsteps=nsteps, dt=dt, drift=drift, gp_mean=gp_mean, gp_cov=gp_cov,
+                           transition_sampler=transition_sampler, transition_logpdf=transition_logpdf,
+                           likelihood_logpdf=likelihood_logpdf, ref_sampler=ref_sampler, fwd_sampler=fwd_sampler,
+                           unpack=unpack, gp_posterior_sampler=gp_posterior_sampler)
+
+
+def main(argv=None):
+    parser = common_args(argparse.ArgumentParser())
+    parser.add_argument('--explicit_backward', action='store_true', default=False)
+    args = parser.parse_args(argv)
+    dev = torch.device('cuda:0')
+    g = sb_setting(args, dev)
+    key, d, y0, ts, nsteps, drift, gp_mean, gp_cov = g.key, g.d, g.y0, g.ts, g.nsteps, g.drift, g.gp_mean, g.gp_cov
+    transition_sampler, transition_logpdf, likelihood_logpdf = g.transition_sampler, g.transition_logpdf, g.likelihood_logpdf
+    ref_sampler, fwd_sampler, unpack = g.ref_sampler, g.fwd_sampler, g.unpack
 
     def gibbs_init(key_):                                                           # :150-161
         key_fwd, key_bwd, key_bf = ops.split(key_, 3)

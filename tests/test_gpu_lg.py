@@ -542,6 +542,20 @@ def test_toy_sb_gibbs_driver(tmp_path, dev):
     assert set(np.load(os.path.join(str(tmp_path), "gibbs-eb-16-666.npz")).files) == {"samples", "gp_mean", "gp_cov"}
 
 
+def test_toy_sb_filter_driver(tmp_path, dev):
+    """examples/toy_sb_filter.py (counterpart of experiments/sb/filter.py: one bootstrap filter per sample on the non-separable
+    Gaussian Schrodinger bridge, forward observation path from a GP-posterior x0 ('proper') or N(0, I) ('heuristic'))."""
+    import os
+    mod = _load_example("toy_sb_filter")
+    for x0 in ("proper", "heuristic"):
+        samples, gp_mean, gp_cov = mod.main(["--d", "3", "--nparticles", "32", "--nsamples", "40", "--x0", x0,
+                                             "--outdir", str(tmp_path), "--quiet"])
+        assert samples.shape == (40, 3) and np.isfinite(samples).all()
+        z = (samples.mean(0) - gp_mean) / np.sqrt(np.diag(gp_cov))
+        assert np.abs(z).max() < 1.5, (x0, z)
+        assert set(np.load(os.path.join(str(tmp_path), f"filter-{x0}-32-666.npz")).files) == {"samples", "gp_mean", "gp_cov"}
+
+
 def test_toy_twisted_driver(tmp_path, dev):
     """examples/toy_twisted.py (counterpart of experiments/toy/gp_twisted.py): twisted SMC with the twisting gradient
     through torch autograd; biased but close to the GP posterior, writes the reference's .npz schema."""
