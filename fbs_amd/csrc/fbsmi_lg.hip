@@ -26,9 +26,12 @@
 //   wide models, 16 < max(du, dv) <= 128           : row-major particles, drift on the f32 matrix cores
 //       (k_lgw_gemm: v_mfma_f32_16x16x4_f32 == ascending fmaf chain); N <= 256: one launch per step with the
 //       prologue fused in; N > 256: norm -> cdf -> k_lgw_anc -> k_lgw_gemm | k_lgw_gemm_fat -> k_lgw_lse
-//   N > 131072                                      : 4 / 16 slots per thread (k_lg_prop<ITEMS>)
+//   N > 131072                                      : 4 / 16 slots per thread, four launches per step: norm -> cdf -> k_lg_heaps
+//       (compact bisection heaps) -> k_lg_propQ (lane-major slots, kill tests first, the killed sources' searches compacted
+//       through an LDS queue); chunks of a thread move as 16-byte accesses
 //   N a power of two, 512 .. 65536                  : TWO kernels per step -- the bisection over the canonical cumsum is a
 //       descent of the summation tree, so norm publishes tree nodes and k_lg_prop1t / k_lg_prop2t walk them; no cdf
+//   N = 2^k + 1 (explicit_final on such an ensemble) : the same two kernels over the first 2^k slots' tree + one extra tile
 #include <hip/hip_runtime.h>
 
 #include <cmath>
