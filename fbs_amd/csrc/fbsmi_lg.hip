@@ -1186,20 +1186,29 @@ __global__ void __launch_bounds__(kBlock) k_lg_propQ(LgDev dd, int s) {
     // ---- phase 2: one queue entry per thread: the redraw from Cat(w) (:73-74)
     const int nq = qn;
     int* anc = reinterpret_cast<int*>(lvs);
+    // two entries per thread and pass, in lockstep: a tile's queue is usually a little longer than the workgroup (~7 % of 4096
+    // slots), and a second pass for its tail would cost the full chain of round trips again
 #pragma unroll 1
-    for (int e0 = 0; e0 < nq; e0 += kBlock) {
-        const int e = e0 + (int)threadIdx.x;
-        const bool on[1] = {e < nq};
-        const int slot = on[0] ? (int)queue[e] : 0;
-        int sc = tile0 + slot - shift;
-        if (sc < 0) sc += N;
-        const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)(on[0] ? sc : 0));
-        const float qK[1] = {last * (1.0f - u2)};
-        int lo[1], hi[1];
-        bisect_lds_levels(N, d.lh_w, heapW, qK[0], lo[0], hi[0]);
+    for (int e0 = 0; e0 < nq; e0 += 2 * kBlock) {
+        bool on[2];
+        int slot[2], lo[2], hi[2];
+        float qK[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = e0 + k * kBlock + (int)threadIdx.x;
+            on[k] = e < nq;
+            slot[k] = on[k] ? (int)queue[e] : 0;
+            int sc = tile0 + slot[k] - shift;
+            if (sc < 0) sc += N;
+            const float u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)(on[k] ? sc : 0));
+            qK[k] = last * (1.0f - u2);
+        }
+        bisect_lds_levels_x2(N, d.lh_w, heapW, qK, lo, hi);
 #pragma unroll 1
-        for (int rem = d.levels - d.lh_w; rem > 0; rem -= 3) bisect_round3_xn<1>(d.cdf, lo, hi, qK, on);
-        if (on[0]) anc[slot] = hi[0];
+        for (int rem = d.levels - d.lh_w; rem > 0; rem -= 3) bisect_round3_xn<2>(d.cdf, lo, hi, qK, on);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (on[k]) anc[slot[k]] = hi[k];
     }
     __syncthreads();
     // ---- phase 3: ancestors' rows, Euler-Maruyama, pin, log-weight
