@@ -499,7 +499,7 @@ def test_two_slot_prop_kernel_matches_oracle(tree, oracle, dev, monkeypatch):
 
 @pytest.mark.parametrize("variant", ["queue", "generic"])
 @pytest.mark.parametrize("toy,N,T,C,eb", [(toy_2d, 200000, 5, 2, True), (toy_4d, 300001, 4, 1, False), (toy_2d, 1100000, 3, 1, True),
-                                         (toy_31, 1048576 + 4096, 2, 1, True)])
+                                         (toy_31, 1048576 + 4096, 2, 1, True), (toy_2d, 1100003, 2, 2, True)])
 def test_several_slots_per_thread_kernels(variant, toy, N, T, C, eb, oracle, dev, monkeypatch):
     """N > 131072: tiles of 1024 / 4096 slots (ITEMS = 4 / 16).  k_lg_heaps + k_lg_propQ (lane-major slots, kill tests first,
     the killed sources' searches compacted through an LDS queue, compact heaps) and the one-slot-after-the-other kernel it
