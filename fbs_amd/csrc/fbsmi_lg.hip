@@ -129,8 +129,19 @@ struct LgDev {
         d.dbg[2 * (i)] = __builtin_amdgcn_s_memrealtime();                               \
         d.dbg[2 * (i) + 1] = __builtin_amdgcn_s_memtime();                               \
     }
+// ... and every workgroup of the LAST step of the LAST sweep of a chain call records its entry / exit time in a slot of its
+// own (in the cdfJ array, which the two-launch step does not use; view 8): how far a launch's first and last workgroup are
+// apart.  (A shared minimum / maximum would serialise 256 atomics at the end of the launch and measure itself.)
+#define FBSMI_SPAN_IN(i, step, last_sweep)                                                                   \
+    if (threadIdx.x == 0 && (step) == d.T - 1 && *d.counter == (last_sweep))                                  \
+        reinterpret_cast<unsigned long long*>(d.cdfJ)[(i) * 1024 + 2 * (blockIdx.x + gridDim.x * blockIdx.y)] = __builtin_amdgcn_s_memrealtime();
+#define FBSMI_SPAN_OUT(i, step, last_sweep)                                                                  \
+    if (threadIdx.x == 0 && (step) == d.T - 1 && *d.counter == (last_sweep))                                  \
+        reinterpret_cast<unsigned long long*>(d.cdfJ)[(i) * 1024 + 2 * (blockIdx.x + gridDim.x * blockIdx.y) + 1] = __builtin_amdgcn_s_memrealtime();
 #else
 #define FBSMI_STAMP(i)
+#define FBSMI_SPAN_IN(i, step, last_sweep)
+#define FBSMI_SPAN_OUT(i, step, last_sweep)
 #endif
 
 // The view of chain c: every per-chain array advanced to that chain's slice (all per-chain arrays
@@ -536,6 +547,7 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
     }
     const LgDev d = chain_view(dd, blockIdx.y);
     if (MODE == 0) { FBSMI_STAMP(2) }
+    if (MODE == 0 && PUB) { FBSMI_SPAN_IN(0, s, 4) }
     __shared__ float xch[4][4];
     const int base = (bx * kBlock + threadIdx.x) * ITEMS;
     const int i_ref = d.bs[MODE == 0 ? s : d.T];
@@ -601,8 +613,16 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
         }
     }
     if (MODE == 0) { FBSMI_STAMP(3) }
+    if (MODE == 0 && PUB) { FBSMI_SPAN_OUT(0, s, 4) }
 }
 
+// (Round 3 also built this kernel with ONE WAVE PER TILE -- four tiles per workgroup, four consecutive elements per lane, the
+// chunk sum as levels 0-1 of the tile tree and the wave's butterfly as levels 2-7, no exchange between waves, the logsumexp combine
+// once per four tiles; bit-exact -- on the theory that launching a quarter of the waves would shorten the launch.  It does not:
+// the workgroups of a launch enter over 0.6-1.1 us whether there are 64 or 256 of them (per-workgroup stamps, tools/stamps), and a
+// lone wave issues one instruction per ~4.4 clocks, so ~1000 instructions in one wave instead of ~370 in each of four cost
+// 3.7 us after the normaliser is known instead of 0.9.  One chain 22.7 against 13.0 us per step, 32 chains 83 against 52.
+// Dropped: on this chip latency wants MORE, thinner waves, not fewer.)
 // ------------------------------------------------------------------------------------------
 // cdf.  MODE 0: cumsum(w) -> cdf and cumsum(J_prob) -> cdfJ; MODE 1: cumsum(rest) -> cdf;
 //       MODE 2: cumsum(w) -> cdf.
@@ -1524,6 +1544,7 @@ __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) 
     __shared__ int Jsh;
     __shared__ float lastsh;
     FBSMI_STAMP(6)
+    FBSMI_SPAN_IN(1, s, 4)
     const int N = d.N, tid = threadIdx.x & (kBlock - 1), half = threadIdx.x / kBlock;
     int bx = blockIdx.x;
     if (dd.pin) {   // (pinned launches use HALVES == 1)
@@ -1674,6 +1695,7 @@ __global__ void __launch_bounds__(kBlock * HALVES) k_lg_prop1t(LgDev dd, int s) 
         d.bsumexp[tileb] = sx;
     }
     FBSMI_STAMP(13)
+    FBSMI_SPAN_OUT(1, s, 4)
 }
 
 // The two-launch step with TWO slots per thread (see k_lg_prop2 below for the pairing): the trees, J and the
@@ -4033,6 +4055,7 @@ int fbsmi_lg_sweep_view(fbsmi_lg_sweep* s, int which, void* dst, int64_t* count,
         case 5: src = d.us_star; n = (int64_t)d.C * (d.T + 1) * d.du; break;
         case 6: src = d.vs; n = (int64_t)d.C * (d.T + 1) * d.dv; break;
         case 7: src = d.dbg; n = 128; break;  // 64 x uint64 as 32-bit words (diagnostic build)
+        case 8: src = d.cdfJ; n = (int64_t)d.C * d.N; break;   // (diagnostic build: per-workgroup entry / exit stamps of the last step)
         default: return fail(FBSMI_ERR_ARG, "lg_sweep_view: unknown view");
     }
     if (!src) n = 0;

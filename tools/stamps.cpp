@@ -32,6 +32,32 @@ int main(int argc, char** argv) {
     int order[] = {2, 14, 3, 4, 15, 16, 5, 6, 7, 8, 9, 10, 11, 12, 13};
     double prev = t0;
     for (int i : order) { printf("%-22s t=%8.0f ns  (+%6.0f)\n", names[i], rt(i) - t0, rt(i) - prev); prev = rt(i); }
+    {   // launch spans of the last step: per-workgroup entry / exit stamps (FBSMI_SPAN_IN / _OUT, view 8)
+        int64_t n8 = 0;
+        fbsmi_lg_sweep_view(s, 8, nullptr, &n8, st);
+        float* d8; (void)hipMalloc(&d8, n8 * 4);
+        fbsmi_lg_sweep_view(s, 8, d8, &n8, st); (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> w(n8 / 2);
+        (void)hipMemcpy(w.data(), d8, (n8 / 2) * 8, hipMemcpyDeviceToHost);
+        // chain 0's array: norm stamps at [0, 1024), prop stamps at [1024, 2048) (u64 units); grids: norm 256 x C blocks of
+        // 256 threads, prop (256 / halves) x C
+        auto span = [&](int base, int blocks, const char* name, double& first_in, double& last_out) {
+            double mn_in = 1e300, mx_in = 0, mn_out = 1e300, mx_out = 0, sum = 0; int cnt = 0;
+            for (int b = 0; b < blocks; ++b) {
+                const double in = (double)w[base + 2 * b] * 10.0, out = (double)w[base + 2 * b + 1] * 10.0;
+                if (in == 0 || out == 0) continue;
+                mn_in = in < mn_in ? in : mn_in; mx_in = in > mx_in ? in : mx_in;
+                mn_out = out < mn_out ? out : mn_out; mx_out = out > mx_out ? out : mx_out; sum += out - in; ++cnt;
+            }
+            printf("%-5s %4d workgroups: first in -> last out %6.0f ns; entries spread over %5.0f ns, exits over %5.0f ns; mean in -> out %6.0f ns\n",
+                   name, cnt, mx_out - mn_in, mx_in - mn_in, mx_out - mn_out, sum / (cnt ? cnt : 1));
+            first_in = mn_in; last_out = mx_out;
+        };
+        double ni, no, pi, po;
+        span(0, 512, "norm", ni, no);
+        span(1024, 512, "prop", pi, po);
+        printf("last norm workgroup out -> first prop workgroup in: %6.0f ns\n", pi - no);
+    }
     double dclk = (double)(h[2 * 13 + 1] - h[2 * 6 + 1]), dns = rt(13) - rt(6);
     printf("shader clock during prop: %.2f GHz (N=%d chains=%d)\n", dclk / dns, N, C);
     return 0;
