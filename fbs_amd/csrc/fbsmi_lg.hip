@@ -3570,7 +3570,8 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
             static const int pin = [] { const char* e = getenv("FBSMI_WIDE_PIN"); return (e ? atoi(e) : 1) && xcd_round_robin_holds(); }();
             // (one chain per launch only: with two chains per launch and two chain groups in flight the pinned step measured
             // 29 us against 16 unpinned, round 3)
-            if (pin && d.C == 1 && gwide.x <= 32)
+            static const int pin_multi = [] { const char* e = getenv("FBSMI_WIDE_PIN_MULTI"); return e ? atoi(e) : 0; }();
+            if (pin && (d.C == 1 || (pin_multi && d.C <= 4)) && gwide.x <= 32)
                 k_lgw_gemm<1><<<dim3(gwide.x * 8, d.C), kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 8 + ((2 * d.c0) & 7));
             else {
                 // (+ extra blocks that draw the next step's noise beside the step: one per 1024 elements, at most 16)
