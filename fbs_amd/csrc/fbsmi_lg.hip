@@ -28,7 +28,8 @@
 //       prologue fused in; N > 256: norm -> cdf -> k_lgw_anc -> k_lgw_gemm | k_lgw_gemm_fat -> k_lgw_lse
 //   N > 131072                                      : 4 / 16 slots per thread, four launches per step: norm -> cdf -> k_lg_heaps
 //       (compact bisection heaps) -> k_lg_propQ (lane-major slots, kill tests first, the killed sources' searches compacted
-//       through an LDS queue); chunks of a thread move as 16-byte accesses
+//       through an LDS queue); chunks of a thread move as 16-byte accesses.  (The draws by a launch of their own, one
+//       Threefry call per element pair, through HBM: measured 10 % slower at 2^22, 6 % at 2^20 -- not kept.)
 //   N a power of two, 512 .. 65536                  : TWO kernels per step -- the bisection over the canonical cumsum is a
 //       descent of the summation tree, so norm publishes tree nodes and k_lg_prop1t / k_lg_prop2t walk them; no cdf
 //   N = 2^k + 1 (explicit_final on such an ensemble) : the same two kernels over the first 2^k slots' tree + one extra tile
