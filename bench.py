@@ -29,6 +29,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -225,17 +226,24 @@ def em_finish_roofline(dev):
                     "pre-drawn it is no faster): see DESIGN.md section 5.0"}
 
 
+def note(rank, msg):
+    """Progress on stderr (rank 0): a long multi-leg run must not look hung to whoever is watching it."""
+    if rank == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def sharded_leg(dev, dist, world, rank, nsteps):
     """BASELINE config 5 as ONE ensemble of 16 384 particles sharded over the ranks (fbs_amd/sharded.py): per SMC step an
-    all_gather of the log-weights, the ancestor rows by all_gather or all_to_all over RCCL, the network and the fused
-    step kernels on the local rows.  Strong scaling: the ensemble is fixed, the per-rank share is 16384 / world."""
+    all_gather of the log-weights, the ancestor rows by all_gather or all_to_all over RCCL or loaded from their owners' windows
+    (exchange="peer": libfbsmi_dist, hipIpc over xGMI), the network and the fused step kernels on the local rows.  Strong scaling: the ensemble is fixed, the per-rank share is 16384 / world."""
     from fbs_amd import image_configs, ops, sharded
     c = image_configs.make("c5", dev, dtype="bf16", nsteps=nsteps)
     N = c.cfg["nparticles"]
     sb = c.sb
     bs = np.zeros(nsteps + 1, np.int32)
     res = {}
-    for exchange in ("all_gather", "all_to_all"):
+    # one rank: nothing is exchanged, the three forms are the same run
+    for exchange in (("all_gather", "all_to_all", "peer") if world > 1 else ("all_gather",)):
         sh = sharded.ParticleShards(N + 1, dist=dist, exchange=exchange)
         run = lambda key: sharded.gibbs_kernel(key, c.x0, c.y0, None, bs, c.ts, sb.fwd_sampler, c.sde, sb.unpack, N,
                                                sb.transition_sampler, sb.transition_logpdf, sb.likelihood_logpdf, sh,
@@ -253,6 +261,7 @@ def sharded_leg(dev, dist, world, rank, nsteps):
             dist.barrier()
         dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
         net_ms = image_configs.network_ms(c)
+        note(rank, f"sharded_c5 {exchange}: {dt / nsteps * 1e3:.1f} ms per step")
         res[exchange] = {"value": float(N) * nsteps / dt, "unit": "particle-steps/s", "ms_per_step": dt / nsteps * 1e3,
                          "network_ms_per_step_rank0": net_ms / nsteps, "rows_per_rank": sh.n,
                          "ancestor_exchange_bytes_received_per_step_rank0": sh.bytes_moved / nsteps,
@@ -286,27 +295,35 @@ def sharded_lg_leg(dev, dist, world, rank, nsteps):
         y0 = torch.zeros(br.dv, device=dev)
         x0 = torch.zeros(du, device=dev)
         bs = np.zeros(nsteps + 1, np.int32)
-        sh = sharded.ParticleShards(N, dist=dist, exchange="auto")
-        run = lambda key: sharded.gibbs_kernel(key, x0, y0, None, bs, ts, br.fwd_sampler, br.sde, br.unpack, N,
-                                               br.transition_sampler, br.transition_logpdf, br.likelihood_logpdf, sh)
-        run(ops.PRNGKey(7))
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        sh.bytes_moved = 0
-        t0 = time.perf_counter()
-        res = run(ops.PRNGKey(8))
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
-        diag = sh.diagnostics.cpu().numpy()
-        out[name] = {"value": float(N) * nsteps / dt, "unit": "particle-steps/s", "ms_per_step": dt / nsteps * 1e3,
-                     "nparticles": N, "du": du, "rows_per_rank": sh.n, "exchange": sh.exchange_for(torch.empty(1, du)),
-                     "ancestor_exchange_bytes_received_per_step_rank0": sh.bytes_moved / nsteps,
-                     "logweight_all_gather_bytes_per_step": 4 * (sh.world - 1) * sh.n,
-                     "ess_last_step": float(diag[-1, 1]), "log_normaliser_sum": float(diag[:, 0].sum()),
-                     "x0_checksum": float(res[0].double().sum().item())}
+        def timed(exchange):
+            sh = sharded.ParticleShards(N, dist=dist, exchange=exchange)
+            run = lambda key: sharded.gibbs_kernel(key, x0, y0, None, bs, ts, br.fwd_sampler, br.sde, br.unpack, N,
+                                                   br.transition_sampler, br.transition_logpdf, br.likelihood_logpdf, sh)
+            run(ops.PRNGKey(7))
+            torch.cuda.synchronize(dev)
+            if dist is not None:
+                dist.barrier()
+            sh.bytes_moved = 0
+            t0 = time.perf_counter()
+            res = run(ops.PRNGKey(8))
+            torch.cuda.synchronize(dev)
+            if dist is not None:
+                dist.barrier()
+            dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
+            diag = sh.diagnostics.cpu().numpy()
+            note(rank, f"sharded_lg {name} {exchange}: {dt / nsteps * 1e3:.2f} ms per step")
+            return {"value": float(N) * nsteps / dt, "unit": "particle-steps/s", "ms_per_step": dt / nsteps * 1e3,
+                    "nparticles": N, "du": du, "rows_per_rank": sh.n, "exchange": sh.exchange_for(torch.empty(1, du)),
+                    "ancestor_exchange_bytes_received_per_step_rank0": sh.bytes_moved / nsteps,
+                    "logweight_all_gather_bytes_per_step": 4 * (sh.world - 1) * sh.n,
+                    "ess_last_step": float(diag[-1, 1]), "log_normaliser_sum": float(diag[:, 0].sum()),
+                    "x0_checksum": float(res[0].double().sum().item())}
+
+        out[name] = timed("auto")
+        if world > 1:                                  # the same ensemble with the rows loaded from their owners' windows
+            p = timed("peer")
+            out[name]["peer"] = {k: p[k] for k in ("value", "ms_per_step", "ancestor_exchange_bytes_received_per_step_rank0",
+                                                   "x0_checksum")}
         del br
         torch.cuda.empty_cache()
     out["workload"] = (f"one linear-Gaussian ensemble over {world} rank(s), closure tier + fbs_amd/sharded.py, gibbs_kernel eb=True "
@@ -335,6 +352,8 @@ def main():
                     help="arithmetic of the image legs' network: f32 = the reference's (the configurations' figures), bf16 = "
                          "autocast fast path; both by default")
     ap.add_argument("--sharded-steps", type=int, default=10, help="SMC steps of the sharded config-5 ensemble (0: skip)")
+    ap.add_argument("--sharded-timeout", type=float, default=900.0,
+                    help="seconds the sharded legs may take on more than one rank before the line is printed without them")
     ap.add_argument("--sharded-lg-steps", type=int, default=20,
                     help="SMC steps of the sharded linear-Gaussian ensembles (`sharded_lg`; 0: skip)")
     ap.add_argument("--no-spill", action="store_true", help="skip the beyond-the-Infinity-Cache leg (`spill`)")
@@ -342,7 +361,7 @@ def main():
 
     # native pieces are built before anything touches the GPU (hipcc / gcc children must not inherit a profiler's preload)
     from fbs_amd import _lib as _fbsmi_lib
-    _fbsmi_lib.build()
+    _fbsmi_lib.build_dist()   # libfbsmi, then the exchange library that links it
     if not args.no_cpu_baseline:
         import oracle as _oracle_build
         _oracle_build.build()
@@ -575,7 +594,20 @@ def main():
                "x0_mean_of_timed_sweeps": float(x0s.float().mean().item())}
         if images:
             out.update(images)
-    # every rank takes part in the sharded ensemble (collectives); rank 0 reports
+    # every rank takes part in the sharded ensemble (collectives); rank 0 reports.  The headline above is already measured:
+    # should an exchange hang on some node, the line is still printed (the sharded legs marked as timed out) and the job ends.
+    def give_up():
+        if rank == 0:
+            out.setdefault("sharded_c5", {"error": f"no result within {args.sharded_timeout} s"})
+            out.setdefault("sharded_lg", {"error": f"no result within {args.sharded_timeout} s"})
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    note(rank, "headline and single-GPU legs done; sharded legs next")
+    watchdog = threading.Timer(args.sharded_timeout, give_up)
+    watchdog.daemon = True
+    if world > 1:
+        watchdog.start()
     shard = None
     if args.sharded_steps > 0 and not args.no_single_chain:
         del sweep
@@ -595,9 +627,11 @@ def main():
         out["sharded_lg"] = shard_lg
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+    watchdog.cancel()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

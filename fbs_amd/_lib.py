@@ -16,6 +16,10 @@ _DEPS = _SRC + [os.path.join(_HERE, "csrc", "fbsmi_device.h"), os.path.join(_HER
                 os.path.join(_HERE, "..", "include", "fbsmi.h"), os.path.join(_HERE, "..", "include", "fbsmi_math.h"),
                 os.path.join(_HERE, "..", "include", "fbsmi_nn.h")]
 LIB_PATH = os.path.join(_HERE, "lib", "libfbsmi.so")
+# include/fbsmi_dist.h: the multi-GPU exchange steps, a library of its own (links librccl + libfbsmi)
+DIST_LIB_PATH = os.path.join(_HERE, "lib", "libfbsmi_dist.so")
+_DIST_SRC = os.path.join(_HERE, "csrc", "fbsmi_dist.hip")
+_DIST_DEPS = [_DIST_SRC, os.path.join(_HERE, "..", "include", "fbsmi_dist.h"), os.path.join(_HERE, "..", "include", "fbsmi.h")]
 
 # -ffp-contract=off is part of the numeric specification (include/fbsmi_math.h)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
@@ -63,6 +67,44 @@ def _compile_and_link(force: bool) -> None:
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
     subprocess.check_call([hip, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
     os.replace(tmp, LIB_PATH)
+
+
+def _rocm_lib_dir() -> str:
+    for cand in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if cand and os.path.exists(os.path.join(cand, "lib", "librccl.so")):
+            return os.path.join(cand, "lib")
+    raise RuntimeError("librccl.so not found: cannot build libfbsmi_dist")
+
+
+def _dist_stale() -> bool:
+    if not os.path.exists(DIST_LIB_PATH):
+        return True
+    t = os.path.getmtime(DIST_LIB_PATH)
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in _DIST_DEPS)
+
+
+def build_dist(force: bool = False) -> str:
+    """Compile libfbsmi_dist.so (after libfbsmi.so, which it links) if it is missing or older than its sources."""
+    build(force)
+    if not (force or _dist_stale()):
+        return DIST_LIB_PATH
+    if not all(os.path.exists(p) for p in _DIST_DEPS):
+        if os.path.exists(DIST_LIB_PATH) and not force:
+            return DIST_LIB_PATH
+        raise RuntimeError("libfbsmi_dist sources missing and no prebuilt library at " + DIST_LIB_PATH)
+    import fcntl
+    with open(DIST_LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or _dist_stale():
+                tmp = f"{DIST_LIB_PATH}.{os.getpid()}.tmp"
+                subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", tmp,
+                                       _DIST_SRC, "-L" + os.path.dirname(LIB_PATH), "-lfbsmi", "-L" + _rocm_lib_dir(), "-lrccl",
+                                       "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + _rocm_lib_dir()])
+                os.replace(tmp, DIST_LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return DIST_LIB_PATH
 
 
 def build(force: bool = False) -> str:
@@ -193,4 +235,51 @@ def call(name: str, *args):
         if rc == -3:
             raise NotImplementedError(msg)
         raise RuntimeError(f"{name} failed ({rc}): {msg}")
+    return rc
+
+
+# ---- include/fbsmi_dist.h ----
+DIST_SIGNATURES = {
+    "fbsmi_dist_abi_version": (C.c_int, []),
+    "fbsmi_dist_last_error": (C.c_char_p, []),
+    "fbsmi_dist_unique_id": (C.c_int, [_vp]),
+    "fbsmi_dist_create": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.POINTER(_vp)]),
+    "fbsmi_dist_destroy": (C.c_int, [_vp]),
+    "fbsmi_dist_shard": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "fbsmi_dist_logsumexp": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "fbsmi_dist_resample_exchange": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_int, _vp]),
+    "fbsmi_dist_window_export": (C.c_int, [_vp, _i64, _vp]),
+    "fbsmi_dist_window_open": (C.c_int, [_vp, _vp]),
+    "fbsmi_dist_window_publish": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "fbsmi_dist_window_read_row": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
+}
+
+_dist = None
+
+
+def dist_lib() -> C.CDLL:
+    """Load libfbsmi_dist.so (and with it librccl); only multi-GPU callers come here."""
+    global _dist
+    if _dist is None:
+        lib()                                                   # libfbsmi first: the dist library links it
+        path = build_dist()
+        try:
+            L = C.CDLL(path)
+        except OSError as e:
+            raise RuntimeError(f"cannot load the HIP extension {path}: {e}") from e
+        for name, (res, args) in DIST_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.fbsmi_dist_abi_version() != 1:
+            raise RuntimeError("libfbsmi_dist ABI version mismatch")
+        _dist = L
+    return _dist
+
+
+def dist_call(name: str, *args):
+    L = dist_lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {L.fbsmi_dist_last_error().decode('utf-8', 'replace')}")
     return rc

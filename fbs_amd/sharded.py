@@ -26,6 +26,15 @@ images) -- runs on the local rows only.  Per SMC step there are exactly two exch
      global rotation (resamplings.py:85), so the traffic is mostly a contiguous shift between two ranks.
    * ``exchange="auto"``: all_to_all for rows of at least 4 KB on more than two ranks (the image configurations),
      all_gather otherwise (the toy's rows are a few bytes: one fixed-shape collective wins).
+   * ``exchange="peer"``: device-initiated (libfbsmi_dist, include/fbsmi_dist.h).  Every rank publishes its rows in a
+     window of its own HBM that the peers have mapped (hipIpc), and one gather kernel LOADS row A[m] straight from its
+     owner over xGMI: only the needed rows move, nothing is packed or counted, the host never waits.  The ordering
+     rides on exchange 1: rows are published before the log-weight collective and read after it; the window is
+     double buffered.  Runs with several ranks on ONE card too (tests/test_gpu_sharded.py).
+
+``DistContext`` wraps the C-ABI of include/fbsmi_dist.h (SURVEY.md 8(b) ``fbsmi_dist_logsumexp`` /
+``fbsmi_dist_resample_exchange``); with ``native_collectives=True`` and the nccl backend, exchange 1 and the all_gather form
+of exchange 2 are libfbsmi_dist's own RCCL calls on a communicator created from an id broadcast through the process group.
 
 Every normalisation also yields the step's log-normaliser increment and ESS (fbsmi_normalise_ess) without any
 further collective -- the weights are replicated; ``shards.diagnostics`` holds them after a pass.
@@ -72,6 +81,120 @@ def gpu_backend():
                            force_move=force_move, randint=ops.randint, normal=ops.normal, fused_step=fused_step)
 
 
+class DistContext:
+    """The C-ABI of include/fbsmi_dist.h for one rank of one ensemble: RCCL collectives and peer windows owned by the
+    library.  `dist` is torch.distributed (it only carries the 128-byte communicator id and the 64-byte window handles)."""
+
+    def __init__(self, n_total: int, dist=None, group=None, rccl: bool = False, device=None):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        self.dist, self.group = dist, group
+        on = dist is not None and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.R = int(n_total)
+        ident = None
+        if rccl:
+            box = [None]
+            if self.rank == 0:
+                buf = C.create_string_buffer(128)
+                _lib.dist_call("fbsmi_dist_unique_id", buf)
+                box[0] = buf.raw
+            if self.world > 1:
+                src = 0 if group is None else dist.get_global_rank(group, 0)
+                dist.broadcast_object_list(box, src=src, group=group)
+            ident = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.dist_call("fbsmi_dist_create", ident, self.rank, self.world, self.R, C.byref(h))
+        self._h = h
+        n, off, cnt = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.dist_call("fbsmi_dist_shard", self._h, C.byref(n), C.byref(off), C.byref(cnt))
+        self.n, self.offset, self.count = n.value, off.value, cnt.value
+        self.has_comm = bool(rccl)
+        self.window_row = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            torch.cuda.synchronize(self.device)
+            self._lib.dist_lib().fbsmi_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def _rows(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise TypeError("libfbsmi_dist moves float32 rows on the GPU")
+        return x.contiguous()
+
+    def logsumexp(self, lw_local: torch.Tensor, log_space: bool = True):
+        """fbsmi_dist_logsumexp -> (normalised (log-)weights of ALL rows, logsumexp, ESS)."""
+        lw = self._rows(lw_local).reshape(-1)
+        if lw.numel() != self.count:
+            raise ValueError(f"{lw.numel()} local log-weights, this rank owns {self.count} rows")
+        out = torch.empty(self.R, dtype=torch.float32, device=lw.device)
+        diag = torch.empty(2, dtype=torch.float32, device=lw.device)
+        self._lib.dist_call("fbsmi_dist_logsumexp", self._h, lw.data_ptr(), 1 if log_space else 0, out.data_ptr(),
+                            diag.data_ptr(), diag.data_ptr() + 4, self._stream())
+        return out, diag[0], diag[1]
+
+    def exchange(self, A_full: torch.Tensor, rows_local: torch.Tensor = None, mode: str = "all_gather", rowshape=None):
+        """fbsmi_dist_resample_exchange -> this rank's (count, ...) ancestor rows."""
+        A = A_full.to(torch.int32).contiguous()
+        if A.numel() != self.R:
+            raise ValueError("the ancestor array must cover the whole ensemble")
+        if mode == "peer":
+            shape = tuple(rowshape)
+            src = 0
+        else:
+            x = self._rows(rows_local)
+            shape, src = tuple(x.shape[1:]), x.data_ptr()
+        d = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        out = torch.empty((self.count,) + shape, dtype=torch.float32, device=A.device)
+        self._lib.dist_call("fbsmi_dist_resample_exchange", self._h, src, A.data_ptr(), d, out.data_ptr(),
+                            1 if mode == "peer" else 0, self._stream())
+        return out
+
+    def open_windows(self, max_row_floats: int):
+        """Allocate this rank's window, swap the IPC handles through the process group, map the peers' windows."""
+        C = self._C
+        mine = C.create_string_buffer(64)
+        with torch.cuda.device(self.device):
+            self._lib.dist_call("fbsmi_dist_window_export", self._h, int(max_row_floats), mine)
+            if self.world > 1:
+                got = [None] * self.world
+                self.dist.all_gather_object(got, mine.raw, group=self.group)
+                allh = C.create_string_buffer(b"".join(got), 64 * self.world)
+            else:
+                allh = C.create_string_buffer(mine.raw, 64)
+            self._lib.dist_call("fbsmi_dist_window_open", self._h, allh)
+        self.window_row = int(max_row_floats)
+
+    def publish(self, rows_local: torch.Tensor):
+        x = self._rows(rows_local)
+        d = int(np.prod(x.shape[1:], dtype=np.int64)) if x.dim() > 1 else 1
+        if x.shape[0] != self.count:
+            raise ValueError(f"{x.shape[0]} rows published, this rank owns {self.count}")
+        self._lib.dist_call("fbsmi_dist_window_publish", self._h, x.data_ptr(), d, self._stream())
+
+    def read_row(self, idx: int, rowshape) -> torch.Tensor:
+        shape = tuple(rowshape)
+        d = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        self._lib.dist_call("fbsmi_dist_window_read_row", self._h, int(idx), d, out.data_ptr(), self._stream())
+        return out
+
+
 class ParticleShards:
     """Slot ownership and the exchanges."""
 
@@ -80,14 +203,14 @@ class ParticleShards:
     # all_gather (one collective of fixed shape, no split sizes on the host)
     AUTO_ROW_BYTES = 4096
 
-    def __init__(self, n_total: int, group=None, dist=None, exchange: str = "all_gather"):
+    def __init__(self, n_total: int, group=None, dist=None, exchange: str = "all_gather", native_collectives: bool = False):
         self.dist = dist
         if dist is not None and dist.is_initialized():
             self.world = dist.get_world_size(group)
             self.rank = dist.get_rank(group)
         else:
             self.world, self.rank = 1, 0
-        if exchange not in ("all_gather", "all_to_all", "auto"):
+        if exchange not in ("all_gather", "all_to_all", "auto", "peer"):
             raise ValueError(f"unknown exchange {exchange}")
         self.group, self.exchange = group, exchange
         self.R = int(n_total)
@@ -99,10 +222,20 @@ class ParticleShards:
             raise ValueError(f"an ensemble of {self.R} rows cannot be split over {self.world} ranks in shards of "
                              f"{self.n} slots: rank {self.world - 1} would own no row")
         self.diagnostics = None                                # per-step (lse, ess) of the last forward pass (device tensors)
-        self.bytes_moved = 0                                   # payload this rank received in ancestor exchanges
+        self._bytes_moved = 0                                  # payload this rank received in ancestor exchanges
+        self._remote_acc = None                                # exchange="peer": the same count kept on the device
         # gloo has no device collectives: GPU tensors are staged through the host (multi-rank rehearsals on one GPU box;
         # the production backend is nccl = RCCL, which takes device pointers)
         self._stage = dist is not None and dist.is_initialized() and dist.get_backend(group) == "gloo"
+        # libfbsmi_dist (include/fbsmi_dist.h): the peer windows of exchange="peer", and -- native_collectives, nccl backend
+        # only -- its own RCCL communicator for the log-weight all-gather and the all_gather form of the row exchange
+        if native_collectives and self.world > 1 and self._stage:
+            raise ValueError("native_collectives needs the nccl backend (RCCL takes device pointers; gloo does not)")
+        self.native = None
+        if exchange == "peer" or native_collectives:
+            self.native = DistContext(self.R, dist=dist if self.world > 1 else None, group=group, rccl=native_collectives)
+            assert (self.native.n, self.native.offset, self.native.count) == (self.n, self.offset, self.count)
+        self.native_collectives = bool(native_collectives)
 
     def _h(self, x: torch.Tensor) -> torch.Tensor:
         return x.cpu() if (self._stage and x.is_cuda) else x
@@ -122,6 +255,34 @@ class ParticleShards:
             return self.exchange
         row_bytes = int(np.prod(us_local.shape[1:])) * us_local.element_size()
         return "all_to_all" if (self.world > 2 and row_bytes >= self.AUTO_ROW_BYTES) else "all_gather"
+
+    @property
+    def bytes_moved(self) -> int:
+        return self._bytes_moved + (int(self._remote_acc) if self._remote_acc is not None else 0)
+
+    @bytes_moved.setter
+    def bytes_moved(self, v: int):
+        self._bytes_moved, self._remote_acc = int(v), None
+
+    def publish(self, us_local: torch.Tensor):
+        """exchange="peer": this rank's rows of the step, into its window (before the step's log-weight collective)."""
+        if self.exchange != "peer":
+            return
+        d = int(np.prod(us_local.shape[1:], dtype=np.int64)) if us_local.dim() > 1 else 1
+        if self.native.window_row == 0:
+            self.native.open_windows(d)
+        elif d > self.native.window_row:
+            raise ValueError(f"rows of {d} floats do not fit the window opened for {self.native.window_row}")
+        self.native.publish(us_local)
+
+    def peer_ancestors(self, us_local: torch.Tensor, A_full: torch.Tensor) -> torch.Tensor:
+        """us_prev_local[m] = us_full[A_full[offset + m]], each row loaded from its owner's window."""
+        out = self.native.exchange(A_full, mode="peer", rowshape=tuple(us_local.shape[1:]))
+        own = (A_full[self.offset:self.offset + self.count].to(torch.int64) // self.n) == self.rank
+        row_bytes = int(np.prod(us_local.shape[1:], dtype=np.int64)) * us_local.element_size()
+        moved = (own.numel() - own.sum()) * row_bytes           # a device scalar: counted without a host sync
+        self._remote_acc = moved if self._remote_acc is None else self._remote_acc + moved
+        return out
 
     def owns(self, slot: int) -> bool:
         return self.offset <= int(slot) < self.offset + self.count
@@ -184,7 +345,7 @@ class ParticleShards:
         recv = torch.empty((self.count, send.shape[1]), dtype=us_local.dtype, device=send.device)
         self.dist.all_to_all_single(recv, send, output_split_sizes=sp[1], input_split_sizes=sp[0], group=self.group)
         recv = recv.to(us_local.device)
-        self.bytes_moved += (self.count - sp[1][self.rank]) * send.shape[1] * send.element_size()
+        self._bytes_moved += (self.count - sp[1][self.rank]) * send.shape[1] * send.element_size()
         out = torch.empty_like(recv)
         out[order] = recv
         return out.reshape((self.count,) + rowshape)
@@ -192,6 +353,8 @@ class ParticleShards:
     def broadcast_row(self, us_local: torch.Tensor, idx: int) -> torch.Tensor:
         """us_full[idx] on every rank."""
         idx = int(idx)
+        if self.exchange == "peer" and self.world > 1:             # the rows as last published: one load from the owner
+            return self.native.read_row(idx, tuple(us_local.shape[1:]))
         src = idx // self.n
         row = us_local[idx - self.offset].clone() if src == self.rank else torch.empty_like(us_local[0])
         if self.world > 1:
@@ -229,6 +392,10 @@ def forward_pass(key, us_star, bs_star, vs, ts, init_sampler, init_likelihood_lo
     diag = []                                      # (logsumexp, ESS) of every normalisation, device scalars (no host sync)
 
     def normalise(lw_local):
+        if sh.native_collectives:                              # fbsmi_dist_logsumexp: ncclAllGather + the same kernel
+            out, lse, ess = sh.native.logsumexp(lw_local, log_space=True)
+            diag.append(torch.stack([lse.reshape(()), ess.reshape(())]))
+            return out
         full = sh.all_gather_rows(lw_local)
         if getattr(be, "normalise_diag", None) is None:
             return be.normalise(full, log_space=True)
@@ -236,6 +403,7 @@ def forward_pass(key, us_star, bs_star, vs, ts, init_sampler, init_likelihood_lo
         diag.append(torch.stack([lse.reshape(()), ess.reshape(())]))
         return out
 
+    sh.publish(us)                                 # exchange="peer": rows into the window BEFORE the step's collective
     log_ws = normalise(lw)                                                            # :155 (replicated)
     exchange = sh.exchange_for(us)
     keys = be.split(key_scan, nsteps)                                                 # :157
@@ -245,10 +413,15 @@ def forward_pass(key, us_star, bs_star, vs, ts, init_sampler, init_likelihood_lo
         v, v_prev, t_prev = vs[k + 1], vs[k], ts[k]
         A = be.cond_resampling(key_resampling, be.exp(log_ws), bs[k], bs[k + 1], True)  # :139 (replicated)
         A_local = A[sh.offset:sh.offset + sh.count]
-        if exchange == "all_gather" or sh.world == 1:                                 # :140: rows by one collective,
+        if exchange == "peer":                                                        # :140: loaded from the owners
+            us_src, A_src = sh.peer_ancestors(us, A), None
+        elif exchange == "all_gather" and sh.native_collectives and sh.world > 1:     # :140: fbsmi_dist_resample_exchange
+            us_src, A_src = sh.native.exchange(A, us, mode="all_gather"), None
+            sh._bytes_moved += (sh.R - sh.count) * int(np.prod(us.shape[1:])) * us.element_size()
+        elif exchange == "all_gather" or sh.world == 1:                               # :140: rows by one collective,
             us_src, A_src = sh.all_gather_rows(us), A_local                           # gathered through A by the consumer
             if sh.world > 1:
-                sh.bytes_moved += (sh.R - sh.count) * int(np.prod(us.shape[1:])) * us.element_size()
+                sh._bytes_moved += (sh.R - sh.count) * int(np.prod(us.shape[1:])) * us.element_size()
         else:                                                                         # :140: only the rows that move
             us_src, A_src = sh.gather_ancestors(us, A, be.take_rows), None
         fused = be.fused_step(closures, us_src, A_src, v, v_prev, t_prev, key_transition, pin_of(k + 1), sh.row_slice,
@@ -261,6 +434,7 @@ def forward_pass(key, us_star, bs_star, vs, ts, init_sampler, init_likelihood_lo
             if sh.owns(bs[k + 1]):
                 us = be.set_row(us, bs[k + 1] - sh.offset, us_star[k + 1])            # :143
             lw = likelihood_logpdf(v, us_prev, v_prev, t_prev, **kwargs)              # :145 (local)
+        sh.publish(us)
         log_ws = normalise(lw)                                                        # :146 (gather + replicated)
     # per normalisation (T + 1 of them): the log-normaliser increment logsumexp(lw) (csmc.py:146 / smc.py:145-146 `c`) and
     # the ESS 1 / sum w^2 -- SURVEY.md 8(b) `out_ess`; replicated on every rank, (T + 1, 2) on the device

@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library loads and exports every symbol include/fbsmi.h (and fbsmi_nn.h) declares; host-side logic
+"""CPU: the C-ABI libraries load and export every symbol include/fbsmi.h, fbsmi_nn.h and fbsmi_dist.h declare; host-side logic
 (key splitting, SDE coefficients, table builder) agrees with the oracle / closed forms; the product
 refuses to run without a GPU instead of falling back."""
 import ctypes
@@ -29,6 +29,25 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/fbsmi.h but not exported"
     assert set(_lib.SIGNATURES) == set(names), set(_lib.SIGNATURES) ^ set(names)
     assert _lib.lib().fbsmi_abi_version() == 1
+
+
+def test_dist_library_exports_every_declared_symbol():
+    """include/fbsmi_dist.h (the multi-GPU exchange steps): the library links librccl and libfbsmi, loads without a GPU, and
+    refuses impossible shardings at creation (no device call before the checks)."""
+    from fbs_amd import _lib
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fbsmi_dist.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(fbsmi_dist_[a-z0-9_]+)\s*\(", text)))
+    L = ctypes.CDLL(_lib.build_dist())
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/fbsmi_dist.h but not exported"
+    assert set(_lib.DIST_SIGNATURES) == set(names), set(_lib.DIST_SIGNATURES) ^ set(names)
+    D = _lib.dist_lib()
+    assert D.fbsmi_dist_abi_version() == 1
+    h = ctypes.c_void_p()
+    for rank, world, rows in ((0, 8, 9), (2, 2, 10), (0, 17, 100), (0, 4, 3)):   # 9 rows over 8 ranks: the last would own none
+        assert D.fbsmi_dist_create(None, rank, world, rows, ctypes.byref(h)) == -1 and not h.value
+        assert len(D.fbsmi_dist_last_error()) > 0
 
 
 def test_host_key_split_matches_oracle_and_golden(oracle):

@@ -1,7 +1,8 @@
 """GPU, 2 and 3 ranks on ONE card (gloo rendezvous, tensors staged through the host -- the production backend is
 nccl = RCCL, which a one-GPU box cannot run with more than one rank): the PRODUCT's sharded path end to end --
 libfbsmi kernels for every local operation, the fused score-network step on each rank's rows with its slice of the
-noise, both ancestor exchanges, explicit_final's ragged N + 1 rows -- must return on every rank exactly what the
+noise, the three ancestor exchanges (the collective two, and libfbsmi_dist's peer windows: every rank's rows in a window the
+other processes map through hipIpc, rows loaded straight from their owner), explicit_final's ragged N + 1 rows -- must return on every rank exactly what the
 unsharded gibbs_kernel returns on one GPU.  The network is a deterministic elementwise stand-in, so the comparison is
 bit for bit (a real UNet's kernels may depend on the batch composition)."""
 import os
@@ -60,7 +61,7 @@ def _worker(rank, world, port, q):
             want = gibbs_kernel(key, x0, y0, None, bs, ts, sb.fwd_sampler, sde, sb.unpack, n, sb.transition_sampler,
                                 sb.transition_logpdf, sb.likelihood_logpdf, marg_y=False, explicit_backward=True,
                                 explicit_final=ef, mask_=mask)
-            for exchange in ("all_gather", "all_to_all"):
+            for exchange in ("all_gather", "all_to_all", "peer"):
                 sh = sharded.ParticleShards(n + (1 if ef else 0), dist=dist, exchange=exchange)
                 got = sharded.gibbs_kernel(key, x0, y0, None, bs, ts, sb.fwd_sampler, sde, sb.unpack, n, sb.transition_sampler,
                                            sb.transition_logpdf, sb.likelihood_logpdf, sh, explicit_final=ef, mask_=mask)
@@ -81,7 +82,7 @@ def _worker(rank, world, port, q):
             bsl = rng.integers(0, N, T2 + 1).astype(np.int32)
             keyl = ops.PRNGKey(77)
             want = br.gibbs_kernel(keyl, x0l, y0l, bsl, N, True, False)
-            for exchange in ("all_gather", "all_to_all", "auto"):
+            for exchange in ("all_gather", "all_to_all", "auto", "peer"):
                 sh = sharded.ParticleShards(N, dist=dist, exchange=exchange)
                 got = sharded.gibbs_kernel(keyl, x0l, y0l, None, bsl, ts2, br.fwd_sampler, br.sde, br.unpack, N,
                                            br.transition_sampler, br.transition_logpdf, br.likelihood_logpdf, sh)
