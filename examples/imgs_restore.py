@@ -5,7 +5,8 @@ mask only; here `--task inpaint` / `--task supr`) and, with `--sb`, of experimen
 flags, same key schedule, same result arrays (`*-gibbs-eb-ef.npy`, `*-filter.npy`, `*-pmcmc-<delta>.npy` of shape
 (nsamples, H, W, C)), written against fbs_amd.  `--method twisted` is experiments/imgs/inpainting_twisted.py (the twisted-SMC
 baseline: whole-image particles, the twisting function's gradient through the score network by torch.autograd; result
-`*-twisted.npy`).  The closures are the bound methods of one fbs_amd.score.ScoreBridge, so
+`*-twisted.npy`), `--method csgm` experiments/imgs/inpainting_csgm.py / supr_csgm.py (conditional score-based sampling: one
+reverse-SDE trajectory with the observed pixels re-noised every step; `*-csgm.npy`).  The closures are the bound methods of one fbs_amd.score.ScoreBridge, so
 every SMC step is two HIP kernels around one network evaluation (PyTorch-ROCm).
 
 The reference loads a trained checkpoint (`./checkpoints/<dataset>_<sde>_<epoch>.npz`, a flat `param` / `ema_param`
@@ -47,7 +48,7 @@ def main(argv=None):
     p.add_argument('--start_from', type=int, default=0)
     p.add_argument('--nparticles', type=int, default=100)
     p.add_argument('--nsamples', type=int, default=100)
-    p.add_argument('--method', type=str, default='gibbs-eb-ef', help="'filter', 'gibbs[-eb][-ef]', 'pmcmc[-delta]', 'twisted'.")
+    p.add_argument('--method', type=str, default='gibbs-eb-ef', help="'filter', 'gibbs[-eb][-ef]', 'pmcmc[-delta]', 'twisted', 'csgm'.")
     p.add_argument('--init_method', type=str, default='filter')
     p.add_argument('--marg', action='store_true', default=False, help='Whether marginalise out the Y path.')
     p.add_argument('--dim', type=int, default=64, help='UNet width (64 in the reference).')
@@ -158,6 +159,15 @@ def main(argv=None):
                 if not args.quiet:
                     print(f'{task} | twisted | iter: {i}')
             np.save(head + '-twisted', restored)
+        elif args.method == 'csgm':                                                  # inpainting_csgm.py:147-158
+            from fbs_amd.csgm import make_image_csgm
+            sampler = make_image_csgm(lambda x, t: run(net, x, t), ds, sde, ts)
+            for i in range(args.nsamples):
+                key, subkey = ops.split(key)
+                restored[i] = to_img(sampler(subkey, test_y0, mask))
+                if not args.quiet:
+                    print(f'{task} | cSGM | iter: {i}')
+            np.save(head + '-csgm', restored)
         elif 'pmcmc' in args.method:
             key, subkey = ops.split(key)
             x0, log_ell, ys = torch.zeros(x_shape, device=dev), 0., sb.fwd_ys_sampler(subkey, test_y0)

@@ -97,6 +97,7 @@ def test_sharded_world1_equals_unsharded_with_unet(oracle, dev):
     ["--task", "inpaint", "--rect_size", "8", "--method", "pmcmc-0.005"],
     ["--task", "supr", "--rate", "4", "--sb", "--method", "gibbs"],
     ["--task", "inpaint", "--rect_size", "15", "--method", "twisted"],
+    ["--task", "supr", "--rate", "2", "--method", "csgm"],
 ])
 def test_image_drivers_run_end_to_end(argv, tmp_path, dev):
     """examples/imgs_restore.py: the counterparts of experiments/imgs/inpainting.py, supr.py and experiments/sb_imgs/supr.py
@@ -108,7 +109,7 @@ def test_image_drivers_run_end_to_end(argv, tmp_path, dev):
                                     "--chunk", "8", "--fp32", "--quiet", "--outdir", str(tmp_path)])
     assert out.shape == (2, 28, 28, 1) and np.isfinite(out).all()
     files = sorted(os.listdir(tmp_path))
-    assert any(f.endswith("-true.npz") for f in files) and any(("gibbs" in f or "filter" in f or "pmcmc" in f or "twisted" in f) and f.endswith(".npy") for f in files)
+    assert any(f.endswith("-true.npz") for f in files) and any(("gibbs" in f or "filter" in f or "pmcmc" in f or "twisted" in f or "csgm" in f) and f.endswith(".npy") for f in files)
 
 
 def test_image_twisted_closures_closed_form_and_driver_pieces(oracle, dev):
@@ -158,3 +159,42 @@ def test_image_twisted_closures_closed_form_and_driver_pieces(oracle, dev):
     # the whole filter + the final categorical draw
     out = tw.conditional_sampler(oracle.PRNGKey(11), y, stratified, mask_=mask)
     assert out.shape == (12, 12, 2) and torch.isfinite(out).all()
+
+
+def test_image_csgm_sampler_closed_form(oracle, dev):
+    """fbs_amd/csgm.py (experiments/imgs/inpainting_csgm.py:88-121) against a float64 replay of the same recursion with a stand-in
+    score that couples the pixels, s(x, t) = -c x + g mean(x): the initial draw, every step's re-noised observation (its own
+    key), the drift through concat / unpack and the Euler-Maruyama noise (the step's slice of ONE draw of (nsteps, *x_shape)) --
+    the reference's key schedule, draws from the oracle's generator."""
+    import math
+    from fbs_amd.csgm import make_image_csgm
+    from fbs_amd.images import ImageRestore
+    from fbs_amd.sdes import StationaryLinLinearSDE, make_linear_sde
+    Tend, T, c, g = 2.0, 9, 0.6, 0.8
+    ts = np.linspace(0, Tend, T + 1)
+    dt = Tend / T
+    sde = StationaryLinLinearSDE(beta_min=0.02, beta_max=5.0, t0=0.0, T=Tend)
+    ds = ImageRestore("inpaint-5", (12, 12, 2), device=dev)
+    mask = ds.gen_mask(oracle.PRNGKey(4))
+    img = torch.from_numpy(np.random.default_rng(1).uniform(size=(12, 12, 2)).astype(np.float32)).to(dev)
+    y0 = ds.unpack(img, mask)[1]
+    sampler = make_image_csgm(lambda x, t: -c * x + g * x.mean(), ds, sde, ts)
+    key = oracle.PRNGKey(21)
+    got = sampler(key, y0, mask)
+    # float64 replay
+    discretise = make_linear_sde(sde)[0]
+    y = y0.cpu().numpy().astype(np.float64)
+    key_init, key_sde = oracle.split(key, 2)
+    u = oracle.normal(key_init, tuple(ds.unobs_shape)).astype(np.float64)
+    key_scan, key_est = oracle.split(key_sde, 2)
+    key_ests = oracle.split(key_est, T)
+    rnds = oracle.normal(key_scan, (T,) + tuple(ds.unobs_shape)).astype(np.float64)
+    for k in range(T):
+        s_ = Tend - ts[k]
+        beta = sde.beta(s_)
+        F, Q = (float(x) for x in discretise(s_, 0.0))
+        v_hat = F * y + math.sqrt(Q) * oracle.normal(key_ests[k], y.shape).astype(np.float64)
+        mean = (u.sum() + v_hat.sum()) / (u.size + v_hat.size)
+        u = u + (0.5 * beta * u + beta * (-c * u + g * mean)) * dt + math.sqrt(beta) * math.sqrt(dt) * rnds[k]
+    assert got.shape == tuple(ds.unobs_shape)
+    np.testing.assert_allclose(got.cpu().numpy(), u, rtol=5e-5, atol=5e-5)
