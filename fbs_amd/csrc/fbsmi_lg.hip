@@ -58,6 +58,9 @@ struct LgDev {
                      // summation tree plus one extra tile that holds the last slot (see tree_build)
     int pin;         // small ensembles: the two-launch step's grids are 8x as wide and only every eighth block works, so the
                      // whole step runs on ONE XCD (blocks b and b + 8 share one) and its hand-offs stay in that XCD's L2
+    int wrot;        // wide models: the LDS tiles' rows are rotated per column plane (wide_rot; FBSMI_WIDE_ROT=0 turns it off)
+    int nz;          // large wide ensembles: the norm / cdf / ancestor launches of a step (a few dozen workgroups each) carry this
+                     // many EXTRA blocks, which draw a third each of the step's noise for the drift kernel (wide_noise_share)
     int N;           // rows of the particle system (nparticles, +1 when explicit_final)
     int nparticles;
     int du, dv, D, T;
@@ -539,8 +542,28 @@ __device__ __forceinline__ float tree_fold(float x, const float (&sib)[8], int l
     return x;
 }
 
+// One third (`part` of 3) of normal(key_transition, (N, du)) of step s into d.xiw, by the `nblk` extra blocks of a launch
+// whose own work needs a few dozen workgroups: elements a and a + n/2 of the draw are the two words of one Threefry call
+// (jax's random_bits), so a thread that owns a pair draws two normals per block-cipher call.
+__device__ __forceinline__ void wide_noise_share(const LgDev& d, int s, uint32_t part, uint32_t blk, uint32_t nblk) {
+    const uint32_t t0 = d.keytab[8 * s + 6], t1 = d.keytab[8 * s + 7];
+    const uint32_t n = (uint32_t)d.N * (uint32_t)d.du, half = (n + 1u) >> 1, third = (half + 2u) / 3u;
+    const uint32_t lo = part * third, hi = lo + third < half ? lo + third : half;
+    for (uint32_t a = lo + blk * kBlock + threadIdx.x; a < hi; a += nblk * kBlock) {
+        const uint32_t b = a + half;
+        uint32_t o0, o1;
+        threefry2x32(t0, t1, a, b < n ? b : 0u, o0, o1);
+        d.xiw[a] = normal_from_bits(o0);
+        if (b < n) d.xiw[b] = normal_from_bits(o1);
+    }
+}
+
 template <int ITEMS, int MODE, bool PUB = false>
 __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
+    if (ITEMS == 1 && MODE == 0 && !PUB && dd.nz && (int)blockIdx.x >= dd.nb) {
+        wide_noise_share(chain_view(dd, blockIdx.y), s, 0, blockIdx.x - dd.nb, gridDim.x - dd.nb);
+        return;
+    }
     int bx = blockIdx.x;
     if (PUB && dd.pin) {
         if (blockIdx.x & 7) return;
@@ -630,6 +653,10 @@ __global__ void __launch_bounds__(kBlock) k_lg_norm(LgDev dd, int s) {
 // ------------------------------------------------------------------------------------------
 template <int ITEMS, int MODE>
 __global__ void __launch_bounds__(kBlock) k_lg_cdf(LgDev dd, int s) {
+    if (ITEMS == 1 && MODE == 0 && dd.nz && (int)blockIdx.x >= dd.nb) {
+        wide_noise_share(chain_view(dd, blockIdx.y), s, 1, blockIdx.x - dd.nb, gridDim.x - dd.nb);
+        return;
+    }
     const LgDev d = chain_view(dd, blockIdx.y);
     if (MODE == 0) { FBSMI_STAMP(4) }
     __shared__ float xch[8][4];
@@ -2089,6 +2116,10 @@ __global__ void __launch_bounds__(kBlock) k_lgw_lse(LgDev dd) {
 
 // ancestors of one step, N > 256: the search half of k_lg_prop1 (J, rotation, kill test, Cat(w) redraw, pin)
 __global__ void __launch_bounds__(kBlock) k_lgw_anc(LgDev dd, int s) {
+    if (dd.nz && (int)blockIdx.x >= dd.nb) {
+        wide_noise_share(chain_view(dd, blockIdx.y), s, 2, blockIdx.x - dd.nb, gridDim.x - dd.nb);
+        return;
+    }
     const LgDev d = chain_view(dd, blockIdx.y);
     __shared__ float heapW[kHeapSizeW], heapJ[kHeapSizeJ], win[kBlock];
     const int N = d.N, t = threadIdx.x;
@@ -2312,6 +2343,25 @@ __device__ __forceinline__ void lgw_fpre_body(const LgDev& d, int kres, bool sto
 // workgroup; 2: the filter prologue (resampling key of step kres), in this workgroup; 3: identity (no
 // resampling in front of this product); 4: d.anc again, with the filters' conventions (k_lgwf_anc).  tr0 / nrt: the row tiles of this launch; emit bit 0: rows < du
 // are written (new particles), bit 1: rows >= du are written (log-density terms).
+// Row rotation of the LDS tiles.  A ds_read_b128 is served in four groups of sixteen lanes that are NOT lanes 0-15, 16-31, ...:
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, {32-35, 44-47, 52-59}, {36-43, 48-51, 60-63} -- every group holds each of the sixteen
+// rows (lane % 16) once, but from TWO column planes g = lane / 16.  Row r of plane g starts at quad (53 r + 13 g) mod 16 of the
+// 64-bank row (S / 4 = 53, Q / 4 = 13 at D = 200): sixteen different quads within a plane, two-way conflicts across the planes of
+// a group (SQ_LDS_BANK_CONFLICT was 37 % of the LDS cycles of the drift kernel).  Plane g therefore keeps matrix row r in LDS row
+// (r + a_g) mod 16 of its 16-row block with a_g chosen so that (S / 4) a_g + (Q / 4) g = 0 mod 16: every plane then maps row r to
+// quad (S / 4) r, and a group's sixteen rows cover the sixteen quads.  (S / 4 is odd, hence invertible mod 16.)
+struct WideRot {
+    int m;   // a_g = (-m g) mod 16 with m = (S / 4)^-1 (Q / 4) mod 16  (no array: a lane-dependent g must not index registers)
+};
+__device__ __forceinline__ WideRot wide_rot(int S, int Q, int on) {
+    if (!on) return WideRot{0};
+    const int s4 = (S >> 2) & 15, q4 = (Q >> 2) & 15;
+    const int inv = (s4 * s4 * s4) & 15;   // s4^-1 mod 16: the units mod 16 have exponent 4, so s4^3 s4 = 1
+    return WideRot{(inv * q4) & 15};
+}
+// LDS row of tile row i (0..31) in column plane g
+__device__ __forceinline__ int wide_row(const WideRot& rot, int i, int g) { return (i & ~15) | ((i - rot.m * g) & 15); }
+
 template <int KIND>
 __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, int nrt, int Kp, int S, int emit, int kres) {
     constexpr bool FUSED = KIND == 1;
@@ -2487,12 +2537,13 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     }
     FBSMI_STAMP(21)
     const int Q = Kp >> 2;
+    const WideRot rot = wide_rot(S, Q, d.wrot);
 #pragma unroll
     for (int q = 0; q < kRows * 4; ++q) {
         const int i = wave + kWaves * (q >> 2);
         const int c = vec4 ? 4 * lane + (q & 3) : lane + 64 * (q & 3);
         if (c < Kp) {
-            const int pos = i * S + (c & 3) * Q + (c >> 2);
+            const int pos = wide_row(rot, i, c & 3) * S + (c & 3) * Q + (c >> 2);
             Gs[pos] = gq[q];
             Zs[pos] = zq[q];
         }
@@ -2501,8 +2552,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     FBSMI_STAMP(22)
     // ---- drift rows: acc = g_r, then acc = fma(G[r][c], z[c], acc) for c = 0 .. D-1, on the matrix cores
     {
-        const float4* ga = reinterpret_cast<const float4*>(Gs + (16 * ar + (lane & 15)) * S + (lane >> 4) * Q);
-        const float4* zb = reinterpret_cast<const float4*>(Zs + jloc * S + (lane >> 4) * Q);
+        const float4* ga = reinterpret_cast<const float4*>(Gs + wide_row(rot, 16 * ar + (lane & 15), lane >> 4) * S + (lane >> 4) * Q);
+        const float4* zb = reinterpret_cast<const float4*>(Zs + wide_row(rot, jloc, lane >> 4) * S + (lane >> 4) * Q);
 #pragma unroll 2
         for (int q4 = 0; q4 < (Q >> 2); ++q4) {
             const float4 a = ga[q4], b = zb[q4];
@@ -2522,7 +2573,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
             const int r = row0 + vv;
             if (r < du) {
                 if (emit & 1) {
-                    float x = (Zs[jloc * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
+                    float x = (Zs[wide_row(rot, jloc, r & 3) * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
                     if (pinned) x = ustar[r];
                     un[(size_t)mo * du + r] = x;
                     if (!FILT && d.uss) d.uss[((size_t)(s + 1) * N + mo) * du + r] = x;
@@ -2596,6 +2647,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     constexpr int kRows = kWideTile / kWaves;
     const bool vec4 = (D & 3) == 0 && (du & 3) == 0;
     const int Q = Kp >> 2;
+    const WideRot rot = wide_rot(S, Q, d.wrot);
     int an[kRows];
 #pragma unroll
     for (int jj = 0; jj < kRows; ++jj) {
@@ -2605,12 +2657,16 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     float gq[kRows * 4], zq[kRows * 4];
     auto load_g = [&](int tr) {
         if (vec4) {
-            const int c = 4 * lane;
+            // branch-free AND select-free: every lane loads from a clamped, always valid address.  (A predicated load costs an
+            // exec-mask save, a branch and a join per row; a select on the loaded value makes the wave wait for the prefetch
+            // before the products instead of after them -- measured 11 % slower.)  What arrives from outside the matrix is
+            // finite model data and never shows: rows >= D of the tile are not emitted, and columns D .. Kp-1 meet the exact
+            // zeros of the Z tile's padding -- fma(x, 0, acc) = acc, as fma(0, 0, acc) was.
+            const int c = 4 * lane < D ? 4 * lane : 0;
 #pragma unroll
             for (int jj = 0; jj < kRows; ++jj) {
                 const int r = kWideTile * tr + wave + kWaves * jj;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < D && c < D) x = *reinterpret_cast<const float4*>(G + (size_t)r * D + c);
+                const float4 x = *reinterpret_cast<const float4*>(G + (size_t)(r < D ? r : D - 1) * D + c);
                 gq[jj * 4 + 0] = x.x; gq[jj * 4 + 1] = x.y; gq[jj * 4 + 2] = x.z; gq[jj * 4 + 3] = x.w;
             }
         } else {
@@ -2622,11 +2678,19 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
         }
     };
     auto store_tile = [&](float* dst, const float (&src)[kRows * 4]) {
+        if (vec4) {   // a lane's four columns 4 lane .. 4 lane + 3 are inside Kp (a multiple of 16) together: ONE branch
+            if (4 * lane < Kp) {
+#pragma unroll
+                for (int q = 0; q < kRows * 4; ++q)
+                    dst[wide_row(rot, wave + kWaves * (q >> 2), q & 3) * S + (q & 3) * Q + lane] = src[q];
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < kRows * 4; ++q) {
             const int i = wave + kWaves * (q >> 2);
-            const int c = vec4 ? 4 * lane + (q & 3) : lane + 64 * (q & 3);
-            if (c < Kp) dst[i * S + (c & 3) * Q + (c >> 2)] = src[q];
+            const int c = lane + 64 * (q & 3);
+            if (c < Kp) dst[wide_row(rot, i, c & 3) * S + (c & 3) * Q + (c >> 2)] = src[q];
         }
     };
     load_g(0);
@@ -2658,8 +2722,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     const int jloc = 16 * ac + (lane & 15);
     const int mo = kWideTile * ts + jloc;
     const bool pinned = mo == j_ref;
-    const float4* ga = reinterpret_cast<const float4*>(Gs + (16 * ar + (lane & 15)) * S + (lane >> 4) * Q);
-    const float4* zb = reinterpret_cast<const float4*>(Zs + jloc * S + (lane >> 4) * Q);
+    const float4* ga = reinterpret_cast<const float4*>(Gs + wide_row(rot, 16 * ar + (lane & 15), lane >> 4) * S + (lane >> 4) * Q);
+    const float4* zb = reinterpret_cast<const float4*>(Zs + wide_row(rot, jloc, lane >> 4) * S + (lane >> 4) * Q);
     const int dvp = (d.dv + 3) & ~3;
 #pragma unroll 1
     for (int tr = 0; tr < nrt; ++tr) {
@@ -2668,8 +2732,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
         mfma_f4 acc;
         float xi[4];
         if (vec4) {   // the step's noise was drawn by k_lgw_noise: one 16-byte load, in flight under the products
-            float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 < du && mo < N) x4 = *reinterpret_cast<const float4*>(d.xiw + (size_t)mo * du + row0);
+            // (clamped address as in load_g; the draws are only used by the lanes that own coordinates of a live slot)
+            const float4 x4 = *reinterpret_cast<const float4*>(d.xiw + ((row0 < du && mo < N) ? (size_t)mo * du + row0 : (size_t)0));
             xi[0] = x4.x; xi[1] = x4.y; xi[2] = x4.z; xi[3] = x4.w;
         }
 #pragma unroll
@@ -2697,7 +2761,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
 #pragma unroll
                 for (int vv = 0; vv < 4; ++vv) {
                     const int r = row0 + vv;
-                    x[vv] = (Zs[jloc * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
+                    x[vv] = (Zs[wide_row(rot, jloc, r & 3) * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
                     if (pinned) x[vv] = ustar[r];
                 }
                 const float4 o4 = make_float4(x[0], x[1], x[2], x[3]);
@@ -2717,7 +2781,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
             for (int vv = 0; vv < 4; ++vv) {
                 const int r = row0 + vv;
                 if (r < du) {
-                    float x = (Zs[jloc * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
+                    float x = (Zs[wide_row(rot, jloc, r & 3) * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
                     if (pinned) x = ustar[r];
                     un[(size_t)mo * du + r] = x;
                     if (d.uss) d.uss[((size_t)(s + 1) * N + mo) * du + r] = x;
@@ -3594,24 +3658,39 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                           (s->two_slot_prop == 1 || (s->two_slot_prop < 0 && (int64_t)nb * d.C >= 5 * 256));
     // N a power of two: the searches walk the summation tree, no cdf launch (k_lg_prop1t)
     const bool tree = s->tree_step && d.trW && !s->generic_prop;
+    // Large wide ensembles (the fat drift kernel): the step's noise is drawn by extra blocks of the three small launches in front
+    // of the drift kernel -- norm, cdf and the ancestor search need a few dozen workgroups each and leave the chip empty --
+    // instead of a launch of its own (k_lgw_noise: ~10 us per step at 10 000 particles).  FBSMI_WIDE_NOISE_FOLD=0: the own launch.
+    const bool fat = d.wide && (int64_t)gwide.x * d.C > 2048;   // enough workgroups to fill the chip twice over: gather once per slot tile
+    static const int noise_fold = [] { const char* e = getenv("FBSMI_WIDE_NOISE_FOLD"); return e ? atoi(e) : 1; }();
+    const bool fold = fat && noise_fold && s->items == 1 && (s->debug_mask & 7) == 7;
+    LgDev dz = d;
+    dim3 gz = gtile;
+    if (fold) {
+        const int64_t third = (((int64_t)d.N * d.du + 1) / 2 + 2) / 3;
+        const int64_t want = (third + kBlock - 1) / kBlock;
+        dz.nz = (int)(want < 1024 ? want : 1024);
+        gz = dim3(gtile.x + dz.nz, gtile.y);
+    }
     for (int k = 0; !one_tile && k < d.T; ++k) {
         if (s->debug_mask & 1) {
             ProfScope p(s, 0, st);
             if (tree) k_lg_norm<1, 0, true><<<dim3(gtile.x * (d.pin ? 8 : 1), d.C), kBlock, 0, st>>>(d, k);
-            else LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 0><<<gtile, kBlock, 0, st>>>(d, k)));
+            else LG_DISPATCH(s, (void)DMAX; (k_lg_norm<ITEMS, 0><<<gz, kBlock, 0, st>>>(dz, k)));
         }
         if ((s->debug_mask & 2) && !tree) {
             ProfScope p(s, 1, st);
-            LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 0><<<gtile, kBlock, 0, st>>>(d, k)));
+            LG_DISPATCH(s, (void)DMAX; (k_lg_cdf<ITEMS, 0><<<gz, kBlock, 0, st>>>(dz, k)));
         }
         if (s->debug_mask & 4) {
             ProfScope p(s, 2, st);
             if (d.wide) {
-                k_lgw_anc<<<gtile, kBlock, 0, st>>>(d, k);
-                if ((int64_t)gwide.x * d.C > 2048) {   // enough workgroups to fill the chip twice over: gather once per slot tile
+                k_lgw_anc<<<gz, kBlock, 0, st>>>(dz, k);
+                if (fat) {
                     const int64_t pairs = ((int64_t)d.N * d.du + 1) / 2;
-                    k_lgw_noise<<<dim3((unsigned)((pairs + kBlock - 1) / kBlock < 4096 ? (pairs + kBlock - 1) / kBlock : 4096), d.C),
-                                  kBlock, 0, st>>>(d, k);
+                    if (!fold)
+                        k_lgw_noise<<<dim3((unsigned)((pairs + kBlock - 1) / kBlock < 4096 ? (pairs + kBlock - 1) / kBlock : 4096), d.C),
+                                      kBlock, 0, st>>>(d, k);
                     k_lgw_gemm_fat<<<dim3((d.N + kWideTile - 1) / kWideTile, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
                 }
                 else
@@ -3756,6 +3835,10 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     d.G = m->G; d.g = m->g; d.sd = m->sd; d.lognorm = m->lognorm; d.F = m->F; d.sqQ = m->sqQ;
     d.levels = bisect_levels(d.N);
     d.wide = wide ? 1 : 0;
+    {
+        static const int wrot = [] { const char* e = getenv("FBSMI_WIDE_ROT"); return e ? atoi(e) : 1; }();
+        d.wrot = wide ? wrot : 0;
+    }
     d.lpw = nullptr;
     if (const char* dm = getenv("FBSMI_DEBUG_STEP_MASK")) s->debug_mask = atoi(dm);
     if (const char* gp = getenv("FBSMI_GENERIC_PROP")) s->generic_prop = atoi(gp) != 0;

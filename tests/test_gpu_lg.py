@@ -194,6 +194,34 @@ def test_wide_batched_chains_match_single_chains(oracle, dev):
             _eq(_np(batch[i][c]), _np(got[i]), f"chain {c} output {i}")
 
 
+@pytest.mark.parametrize("d,C,N,T", [(100, 1, 100, 7), (24, 1, 40, 9), (40, 2, 100, 6), (24, 4, 300, 5), (20, 1, 3000, 3)])
+def test_wide_chained_sweeps_match_oracle(d, C, N, T, oracle, dev):
+    """The driver loop (gp_gibbs.py:182-187) on wide models: sweeps chained inside the engine -- the one-launch step's noise
+    is drawn one step AHEAD (by idle / extra blocks of the previous launch, across the sweep boundary by the sweep's first
+    kernels), a single chain's launches are pinned to one XCD -- against the oracle's chain, sample for sample."""
+    toy = toy_gp(d)
+    ts = np.linspace(0, 1.0, T + 1)
+    br = _bridge(toy, ts, dev)
+    om = oracle_model_from(oracle, br)
+    rng = np.random.default_rng(d + C + N)
+    nsw = 4
+    if C == 1:
+        x0 = rng.normal(size=d).astype(np.float32)
+        bs = rng.integers(0, N, T + 1).astype(np.int32)
+        sweep = br.sweep_handle(N, True, False)
+        key, x0f, bsf, x0s = sweep.chain(oracle.PRNGKey(31), x0, toy["y0"], bs, nsw)
+        okey, ox0, obs, oout = oracle.gibbs_chain_lg(om, oracle.PRNGKey(31), x0, toy["y0"], bs, N, nsw)
+    else:
+        x0 = rng.normal(size=(C, d)).astype(np.float32)
+        bs = rng.integers(0, N, (C, T + 1)).astype(np.int32)
+        sweep = br.sweep_handle(N, True, False, nchains=C)
+        key, x0f, bsf, x0s = sweep.chain(oracle.PRNGKey(31), x0, toy["y0"], bs, nsw)
+        okey, ox0, obs, oout = oracle.gibbs_chains_lg(om, oracle.PRNGKey(31), x0, toy["y0"], bs, N, nsw)
+    np.testing.assert_array_equal(key, okey)
+    _eq(_np(x0s).reshape(np.asarray(oout).shape), oout, "chain samples")
+    _eq(_np(bsf).reshape(np.asarray(obs).shape), obs, "final bs_star")
+
+
 @pytest.mark.parametrize("toy,N,T", [(toy_2d, 64, 30), (toy_4d, 100, 20)])
 def test_fused_forward_pass_paths_match_oracle(toy, N, T, oracle, dev):
     """As / uss / log_wss of csmc.forward_pass (csmc.py:161-164) on the stored-path variant."""
