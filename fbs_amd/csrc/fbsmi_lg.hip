@@ -58,7 +58,6 @@ struct LgDev {
                      // summation tree plus one extra tile that holds the last slot (see tree_build)
     int pin;         // small ensembles: the two-launch step's grids are 8x as wide and only every eighth block works, so the
                      // whole step runs on ONE XCD (blocks b and b + 8 share one) and its hand-offs stay in that XCD's L2
-    int wrot;        // wide models: the LDS tiles' rows are rotated per column plane (wide_rot; FBSMI_WIDE_ROT=0 turns it off)
     int nz;          // large wide ensembles: the norm / cdf / ancestor launches of a step (a few dozen workgroups each) carry this
                      // many EXTRA blocks, which draw a third each of the step's noise for the drift kernel (wide_noise_share)
     int N;           // rows of the particle system (nparticles, +1 when explicit_final)
@@ -2334,33 +2333,25 @@ __device__ __forceinline__ void lgw_fpre_body(const LgDev& d, int kres, bool sto
 }
 
 // The drift product and what hangs on it.  nrt = row tiles = ceil(D / 32); Kp = D rounded up to a multiple of
-// 16, Q = Kp / 4.  LDS tiles are [32][S] with column c stored at (c % 4) * Q + c / 4: lane group g of an
-// MFMA (which supplies column 4q + g of instruction q) then finds its columns of four consecutive
-// instructions in one aligned float4.  S = Kp + 4, i.e. S / 4 odd: the 16 lanes of a ds_read_b128 pass (16 consecutive rows,
-// one aligned float4 each) start at 16 different bank quads and cover all 64 banks.  (S used to be padded up to 4 mod 64 --
-// 260 floats for D = 200 --; at 212 a large-ensemble workgroup needs 54 KB instead of 66 and three fit a CU.)
+// 16; the two LDS tiles (32 rows of G_s, 32 gathered slots of z) are laid out by wide_pos (below), S floats per plane row.
 // KIND: where the ancestors come from -- 0: d.anc (k_lgw_anc); 1: the Gibbs step prologue, in this
 // workgroup; 2: the filter prologue (resampling key of step kres), in this workgroup; 3: identity (no
 // resampling in front of this product); 4: d.anc again, with the filters' conventions (k_lgwf_anc).  tr0 / nrt: the row tiles of this launch; emit bit 0: rows < du
 // are written (new particles), bit 1: rows >= du are written (log-density terms).
-// Row rotation of the LDS tiles.  A ds_read_b128 is served in four groups of sixteen lanes that are NOT lanes 0-15, 16-31, ...:
-// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, {32-35, 44-47, 52-59}, {36-43, 48-51, 60-63} -- every group holds each of the sixteen
-// rows (lane % 16) once, but from TWO column planes g = lane / 16.  Row r of plane g starts at quad (53 r + 13 g) mod 16 of the
-// 64-bank row (S / 4 = 53, Q / 4 = 13 at D = 200): sixteen different quads within a plane, two-way conflicts across the planes of
-// a group (SQ_LDS_BANK_CONFLICT was 37 % of the LDS cycles of the drift kernel).  Plane g therefore keeps matrix row r in LDS row
-// (r + a_g) mod 16 of its 16-row block with a_g chosen so that (S / 4) a_g + (Q / 4) g = 0 mod 16: every plane then maps row r to
-// quad (S / 4) r, and a group's sixteen rows cover the sixteen quads.  (S / 4 is odd, hence invertible mod 16.)
-struct WideRot {
-    int m;   // a_g = (-m g) mod 16 with m = (S / 4)^-1 (Q / 4) mod 16  (no array: a lane-dependent g must not index registers)
-};
-__device__ __forceinline__ WideRot wide_rot(int S, int Q, int on) {
-    if (!on) return WideRot{0};
-    const int s4 = (S >> 2) & 15, q4 = (Q >> 2) & 15;
-    const int inv = (s4 * s4 * s4) & 15;   // s4^-1 mod 16: the units mod 16 have exponent 4, so s4^3 s4 = 1
-    return WideRot{(inv * q4) & 15};
-}
-// LDS row of tile row i (0..31) in column plane g
-__device__ __forceinline__ int wide_row(const WideRot& rot, int i, int g) { return (i & ~15) | ((i - rot.m * g) & 15); }
+// LDS tiles of the drift kernels: [4 column planes][32 rows][S] floats, element (row i, column c) at ((c % 4) * 32 + i) * S + c / 4
+// -- lane group g = lane / 16 of an MFMA (which supplies column 4q + g of instruction q) finds its columns of four consecutive
+// instructions in one aligned float4 of plane g.  S = Kp / 4 (rounded up to 4 mod 8, so that S / 4 is odd).  A ds_read_b128 is
+// served in four groups of sixteen lanes -- NOT lanes 0-15, 16-31, ... but {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, {32-35,
+// 44-47, 52-59}, {36-43, 48-51, 60-63}: every group holds each of the sixteen rows (lane % 16) once, from two planes.  A plane is
+// 32 S floats = a multiple of 64 banks, so planes do not shift the banks, and row r starts at bank quad (S / 4) r mod 16: the
+// sixteen rows of a group cover the sixteen quads, conflict-free.  (The rows-outside layout [32][4 planes] this replaces put plane g
+// 13 g quads further on: two-way conflicts in every group, 37 % of the LDS cycles of the large-ensemble kernel -- and needed
+// 54 272 bytes for its two tiles at D = 200, of which a CU holds TWO, whatever the occupancy query says: tools/occ_probe.  The
+// planes-outside form needs 53 248, and three workgroups per CU fit: 626 workgroups at 10 000 particles x 2 chains run in one
+// round instead of two.)
+__device__ __forceinline__ int wide_pos(int i, int c, int S) { return ((c & 3) * kWideTile + i) * S + (c >> 2); }
+static inline int wide_plane_row(int Kp) { return ((Kp / 4) & 4) ? Kp / 4 : Kp / 4 + 4; }   // S: Kp / 4 made 4 mod 8
+static inline size_t wide_lds_bytes(int S) { return sizeof(float) * 2 * 4 * kWideTile * (size_t)S; }
 
 template <int KIND>
 __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, int nrt, int Kp, int S, int emit, int kres) {
@@ -2408,7 +2399,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     __shared__ LgwPreLds pre;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* Gs = dyn;                    // [32 rows][S]: rows 32*tr .. of G_s
-    float* Zs = dyn + kWideTile * S;    // [32 slots][S]: z = (u[ancestor], v_prev)
+    float* Zs = dyn + 4 * kWideTile * S;    // [32 slots][S]: z = (u[ancestor], v_prev)
     const int N = d.N, du = d.du, D = d.D;
     const int ts = bx / nrt, tr = tr0 + (bx - ts * nrt);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -2537,13 +2528,12 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     }
     FBSMI_STAMP(21)
     const int Q = Kp >> 2;
-    const WideRot rot = wide_rot(S, Q, d.wrot);
 #pragma unroll
     for (int q = 0; q < kRows * 4; ++q) {
         const int i = wave + kWaves * (q >> 2);
         const int c = vec4 ? 4 * lane + (q & 3) : lane + 64 * (q & 3);
         if (c < Kp) {
-            const int pos = wide_row(rot, i, c & 3) * S + (c & 3) * Q + (c >> 2);
+            const int pos = wide_pos(i, c, S);
             Gs[pos] = gq[q];
             Zs[pos] = zq[q];
         }
@@ -2552,8 +2542,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     FBSMI_STAMP(22)
     // ---- drift rows: acc = g_r, then acc = fma(G[r][c], z[c], acc) for c = 0 .. D-1, on the matrix cores
     {
-        const float4* ga = reinterpret_cast<const float4*>(Gs + wide_row(rot, 16 * ar + (lane & 15), lane >> 4) * S + (lane >> 4) * Q);
-        const float4* zb = reinterpret_cast<const float4*>(Zs + wide_row(rot, jloc, lane >> 4) * S + (lane >> 4) * Q);
+        const float4* ga = reinterpret_cast<const float4*>(Gs + wide_pos(16 * ar + (lane & 15), lane >> 4, S));
+        const float4* zb = reinterpret_cast<const float4*>(Zs + wide_pos(jloc, lane >> 4, S));
 #pragma unroll 2
         for (int q4 = 0; q4 < (Q >> 2); ++q4) {
             const float4 a = ga[q4], b = zb[q4];
@@ -2573,7 +2563,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
             const int r = row0 + vv;
             if (r < du) {
                 if (emit & 1) {
-                    float x = (Zs[wide_row(rot, jloc, r & 3) * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
+                    float x = (Zs[wide_pos(jloc, r, S)] + acc[vv] * d.dt) + sd * xi[vv];
                     if (pinned) x = ustar[r];
                     un[(size_t)mo * du + r] = x;
                     if (!FILT && d.uss) d.uss[((size_t)(s + 1) * N + mo) * du + r] = x;
@@ -2629,7 +2619,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     const LgDev d = chain_view(dd, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* Gs = dyn;
-    float* Zs = dyn + kWideTile * S;
+    float* Zs = dyn + 4 * kWideTile * S;
     const int N = d.N, du = d.du, D = d.D;
     const int ts = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -2647,7 +2637,6 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     constexpr int kRows = kWideTile / kWaves;
     const bool vec4 = (D & 3) == 0 && (du & 3) == 0;
     const int Q = Kp >> 2;
-    const WideRot rot = wide_rot(S, Q, d.wrot);
     int an[kRows];
 #pragma unroll
     for (int jj = 0; jj < kRows; ++jj) {
@@ -2682,7 +2671,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
             if (4 * lane < Kp) {
 #pragma unroll
                 for (int q = 0; q < kRows * 4; ++q)
-                    dst[wide_row(rot, wave + kWaves * (q >> 2), q & 3) * S + (q & 3) * Q + lane] = src[q];
+                    dst[wide_pos(wave + kWaves * (q >> 2), q & 3, S) + lane] = src[q];
             }
             return;
         }
@@ -2690,7 +2679,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
         for (int q = 0; q < kRows * 4; ++q) {
             const int i = wave + kWaves * (q >> 2);
             const int c = lane + 64 * (q & 3);
-            if (c < Kp) dst[wide_row(rot, i, c & 3) * S + (c & 3) * Q + (c >> 2)] = src[q];
+            if (c < Kp) dst[wide_pos(i, c, S)] = src[q];
         }
     };
     load_g(0);
@@ -2722,33 +2711,68 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     const int jloc = 16 * ac + (lane & 15);
     const int mo = kWideTile * ts + jloc;
     const bool pinned = mo == j_ref;
-    const float4* ga = reinterpret_cast<const float4*>(Gs + wide_row(rot, 16 * ar + (lane & 15), lane >> 4) * S + (lane >> 4) * Q);
-    const float4* zb = reinterpret_cast<const float4*>(Zs + wide_row(rot, jloc, lane >> 4) * S + (lane >> 4) * Q);
+    const float4* ga = reinterpret_cast<const float4*>(Gs + wide_pos(16 * ar + (lane & 15), lane >> 4, S));
+    const float4* zb = reinterpret_cast<const float4*>(Zs + wide_pos(jloc, lane >> 4, S));
     const int dvp = (d.dv + 3) & ~3;
+    // Vector-memory loads return in order, so a wait for the LAST load issued waits for all of them: the accumulators' initial
+    // values g[r] used to be loaded after the next G tile had been asked for, and the products started only when that whole
+    // prefetch had arrived (half of the kernel's wave-cycles were such waits).  Now the bias of tile tr + 1 is fetched one tile
+    // ahead, and within a tile the loads go out in the order of their use: next bias, this tile's noise, next G tile.
+    float gb[4];
+#pragma unroll
+    for (int vv = 0; vv < 4; ++vv) {
+        const int r = 16 * ar + 4 * (lane >> 4) + vv;
+        gb[vv] = g[r < D ? r : D - 1];   // (rows >= D are never emitted: any finite value will do)
+    }
 #pragma unroll 1
     for (int tr = 0; tr < nrt; ++tr) {
-        if (tr + 1 < nrt) load_g(tr + 1);   // in flight while this tile is multiplied
         const int row0 = kWideTile * tr + 16 * ar + 4 * (lane >> 4);
+        float gbn[4];
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) {
+            const int r = row0 + kWideTile + vv;
+            gbn[vv] = g[r < D ? r : D - 1];
+        }
         mfma_f4 acc;
         float xi[4];
-        if (vec4) {   // the step's noise was drawn by k_lgw_noise: one 16-byte load, in flight under the products
+        if (vec4) {   // the step's noise: one 16-byte load, in flight under the products
             // (clamped address as in load_g; the draws are only used by the lanes that own coordinates of a live slot)
             const float4 x4 = *reinterpret_cast<const float4*>(d.xiw + ((row0 < du && mo < N) ? (size_t)mo * du + row0 : (size_t)0));
             xi[0] = x4.x; xi[1] = x4.y; xi[2] = x4.z; xi[3] = x4.w;
-        }
+        } else {
 #pragma unroll
-        for (int vv = 0; vv < 4; ++vv) {
-            const int r = row0 + vv;
-            acc[vv] = r < D ? g[r] : 0.0f;
-            if (!vec4) xi[vv] = (r < du && mo < N) ? d.xiw[(size_t)mo * du + r] : 0.0f;
+            for (int vv = 0; vv < 4; ++vv) xi[vv] = (row0 + vv < du && mo < N) ? d.xiw[(size_t)mo * du + row0 + vv] : 0.0f;
         }
-#pragma unroll 2
-        for (int q4 = 0; q4 < (Q >> 2); ++q4) {
-            const float4 a = ga[q4], b = zb[q4];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+        if (tr + 1 < nrt) load_g(tr + 1);   // in flight while this tile is multiplied
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) acc[vv] = gb[vv];
+        // the operands of the NEXT four products travel from LDS while the current four (a dependent chain, 4 x 8 passes) run:
+        // two operand sets in turn, the scheduling barriers keep each read in front of the products it overlaps (left alone the
+        // compiler rotates the read to the top of the next iteration and waits for it there)
+        {
+            const int nq = Q >> 2;
+            float4 a0 = ga[0], b0 = zb[0];
+#pragma unroll 1
+            for (int q4 = 0; q4 < nq; q4 += 2) {
+                const int q1 = q4 + 1 < nq ? q4 + 1 : q4, q2 = q4 + 2 < nq ? q4 + 2 : q4;
+                const float4 a1 = ga[q1], b1 = zb[q1];
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q4 + 1 < nq) {
+                    a0 = ga[q2];
+                    b0 = zb[q2];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         if (tr == 0) { FBSMI_STAMP(22) }
         if (tr == 5) { FBSMI_STAMP(26) }
@@ -2761,7 +2785,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
 #pragma unroll
                 for (int vv = 0; vv < 4; ++vv) {
                     const int r = row0 + vv;
-                    x[vv] = (Zs[wide_row(rot, jloc, r & 3) * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
+                    x[vv] = (Zs[wide_pos(jloc, r, S)] + acc[vv] * d.dt) + sd * xi[vv];
                     if (pinned) x[vv] = ustar[r];
                 }
                 const float4 o4 = make_float4(x[0], x[1], x[2], x[3]);
@@ -2781,7 +2805,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
             for (int vv = 0; vv < 4; ++vv) {
                 const int r = row0 + vv;
                 if (r < du) {
-                    float x = (Zs[wide_row(rot, jloc, r & 3) * S + (r & 3) * Q + (r >> 2)] + acc[vv] * d.dt) + sd * xi[vv];
+                    float x = (Zs[wide_pos(jloc, r, S)] + acc[vv] * d.dt) + sd * xi[vv];
                     if (pinned) x = ustar[r];
                     un[(size_t)mo * du + r] = x;
                     if (d.uss) d.uss[((size_t)(s + 1) * N + mo) * du + r] = x;
@@ -2801,6 +2825,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
         }
         if (tr == 0) { FBSMI_STAMP(24) }
         if (tr == 4) { FBSMI_STAMP(25) }
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) gb[vv] = gbn[vv];
     }
     FBSMI_STAMP(30)
 }
@@ -3614,8 +3640,8 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     k_lg_path<<<dim3(gpath, d.C), 64, 0, st>>>(d, 0);
     // wide models: MFMA drift, one workgroup per (32 slots, 32 drift rows)
     const int w_nrt = (d.D + kWideTile - 1) / kWideTile, w_Kp = (d.D + 15) / 16 * 16;
-    const int w_S = w_Kp + 4;   // S / 4 odd (Kp is a multiple of 16)
-    const size_t w_lds = sizeof(float) * 2 * kWideTile * (size_t)w_S;
+    const int w_S = wide_plane_row(w_Kp);
+    const size_t w_lds = wide_lds_bytes(w_S);
     const dim3 gwide(((d.N + kWideTile - 1) / kWideTile) * w_nrt, d.C);
     if (d.wide) {
         k_lgw_init<<<gtile, kBlock, 0, st>>>(d);
@@ -3835,10 +3861,6 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     d.G = m->G; d.g = m->g; d.sd = m->sd; d.lognorm = m->lognorm; d.F = m->F; d.sqQ = m->sqQ;
     d.levels = bisect_levels(d.N);
     d.wide = wide ? 1 : 0;
-    {
-        static const int wrot = [] { const char* e = getenv("FBSMI_WIDE_ROT"); return e ? atoi(e) : 1; }();
-        d.wrot = wide ? wrot : 0;
-    }
     d.lpw = nullptr;
     if (const char* dm = getenv("FBSMI_DEBUG_STEP_MASK")) s->debug_mask = atoi(dm);
     if (const char* gp = getenv("FBSMI_GENERIC_PROP")) s->generic_prop = atoi(gp) != 0;
@@ -3976,8 +3998,7 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     if (wide) {
         // The attribute belongs to the function, not to the handle: always ask for the largest tile pair any model can
         // need (D = 256), or a later handle with a smaller model would lower the limit under an earlier one.
-        constexpr int kKpMax = 256, kSMax = kKpMax + 4;
-        const int lds = (int)(sizeof(float) * 2 * kWideTile * kSMax);
+        const int lds = (int)wide_lds_bytes(wide_plane_row(256));
         hipError_t e = hipFuncSetAttribute((const void*)k_lgw_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -4175,8 +4196,8 @@ int enqueue_filter(fbsmi_lg_filter* f, hipStream_t st) {
     }
     if (d.wide) {
         // N <= 256: a launch = [filter prologue +] drift product
-        const int nrt = (d.D + kWideTile - 1) / kWideTile, Kp = (d.D + 15) / 16 * 16, S = Kp + 4;
-        const size_t lds = sizeof(float) * 2 * kWideTile * (size_t)S;
+        const int nrt = (d.D + kWideTile - 1) / kWideTile, Kp = (d.D + 15) / 16 * 16, S = wide_plane_row(Kp);
+        const size_t lds = wide_lds_bytes(S);
         const int nst = (d.N + kWideTile - 1) / kWideTile;
         const int u_tiles = (d.du + kWideTile - 1) / kWideTile;   // row tiles holding rows < du
         const int v_tile0 = d.du / kWideTile;                     // first row tile holding rows >= du
