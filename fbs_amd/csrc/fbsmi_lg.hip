@@ -2528,14 +2528,26 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     }
     FBSMI_STAMP(21)
     const int Q = Kp >> 2;
+    if (vec4) {
+        // a lane's four columns 4 lane .. 4 lane + 3 lie inside Kp (a multiple of 16) together: ONE branch for the 64 stores (they
+        // used to be 64 predicated stores: an exec-mask save, a branch and a join each).  The G tile, which has been here since
+        // the prologue, goes first: its stores run while the ancestor rows are still on their way.
+        if (4 * lane < Kp) {
 #pragma unroll
-    for (int q = 0; q < kRows * 4; ++q) {
-        const int i = wave + kWaves * (q >> 2);
-        const int c = vec4 ? 4 * lane + (q & 3) : lane + 64 * (q & 3);
-        if (c < Kp) {
-            const int pos = wide_pos(i, c, S);
-            Gs[pos] = gq[q];
-            Zs[pos] = zq[q];
+            for (int q = 0; q < kRows * 4; ++q) Gs[wide_pos(wave + kWaves * (q >> 2), q & 3, S) + lane] = gq[q];
+#pragma unroll
+            for (int q = 0; q < kRows * 4; ++q) Zs[wide_pos(wave + kWaves * (q >> 2), q & 3, S) + lane] = zq[q];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kRows * 4; ++q) {
+            const int i = wave + kWaves * (q >> 2);
+            const int c = lane + 64 * (q & 3);
+            if (c < Kp) {
+                const int pos = wide_pos(i, c, S);
+                Gs[pos] = gq[q];
+                Zs[pos] = zq[q];
+            }
         }
     }
     __syncthreads();
@@ -2556,7 +2568,34 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     FBSMI_STAMP(23)
     // ---- rows < du: transition_sampler (gp_gibbs.py:120-122) + pin (csmc.py:143);
     //      rows >= du: the terms of likelihood_logpdf (gp_gibbs.py:131-135, csmc.py:145)
-    if (mo < N) {
+    if (mo < N && vec4) {
+        // the lane's four rows are consecutive and du, D are multiples of four: all four are coordinates, or all four are
+        // observation rows, or none exists -- and each kind leaves as ONE 16-byte store
+        const bool pinned = mo == j_ref;
+        if (row0 < du) {
+            if (emit & 1) {
+                float x[4];
+#pragma unroll
+                for (int vv = 0; vv < 4; ++vv) {
+                    const int r = row0 + vv;
+                    x[vv] = (Zs[wide_pos(jloc, r, S)] + acc[vv] * d.dt) + sd * xi[vv];
+                    if (pinned) x[vv] = ustar[r];
+                }
+                const float4 o4 = make_float4(x[0], x[1], x[2], x[3]);
+                *reinterpret_cast<float4*>(un + (size_t)mo * du + row0) = o4;
+                if (!FILT && d.uss) *reinterpret_cast<float4*>(d.uss + ((size_t)(s + 1) * N + mo) * du + row0) = o4;
+                if (FILT && d.flow == 1 && s == d.T - 1) *reinterpret_cast<float4*>(d.usT + (size_t)mo * du + row0) = o4;
+            }
+        } else if (row0 < D && (emit & 2)) {
+            const int rv0 = row0 - du;
+            const float4 vt = *reinterpret_cast<const float4*>(v + rv0), vp = *reinterpret_cast<const float4*>(v_prev + rv0);
+            const float tg[4] = {vt.x, vt.y, vt.z, vt.w}, pv[4] = {vp.x, vp.y, vp.z, vp.w};
+            float l4[4];
+#pragma unroll
+            for (int vv = 0; vv < 4; ++vv) l4[vv] = norm_logpdf(tg[vv], pv[vv] + acc[vv] * d.dt, sd2, lognorm);
+            *reinterpret_cast<float4*>(d.lpw + (size_t)mo * ((d.dv + 3) & ~3) + rv0) = make_float4(l4[0], l4[1], l4[2], l4[3]);
+        }
+    } else if (mo < N) {
         const bool pinned = mo == j_ref;
 #pragma unroll
         for (int vv = 0; vv < 4; ++vv) {
@@ -2615,8 +2654,19 @@ __global__ void __launch_bounds__(kBlock) k_lgw_noise(LgDev dd, int s) {
 // per row tile), the next G tile travelling to registers while the matrix cores work on the current one.
 // Ancestors from k_lgw_anc, all rows emitted.  66 KB of LDS: two workgroups per CU, so one's noise draws
 // (VALU) overlap the other's MFMAs.
+// (Measured, round 3, 10 000 particles x 2 chains = 626 workgroups, per-workgroup entry / exit stamps of the diagnostic build:
+// all enter within 1.1 us; the CUs that hold three of them finish after 33 us, those with two after 22 -- 11 us of CU time per
+// workgroup either way, i.e. the CU is saturated by two: per row tile a wave issues ~290 vector instructions besides its 52
+// dependent products, and the two kinds overlap little.  Starting the workgroups of a CU out of phase (s_sleep by b / 256) made
+// it slower.)
 __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nrt, int Kp, int S) {
     const LgDev d = chain_view(dd, blockIdx.y);
+#ifdef FBSMI_STAMPS
+    // diagnostic build: every workgroup of the last step's launch records its entry / exit time (view 9; the second noise slot of
+    // chain 0, which this path does not use) -- how the launch's workgroups are spread over its duration
+    unsigned long long* span = reinterpret_cast<unsigned long long*>(dd.xiw + (size_t)dd.N * dd.du) + 2 * (blockIdx.x + gridDim.x * blockIdx.y);
+    if (threadIdx.x == 0 && s == d.T - 1) span[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* Gs = dyn;
     float* Zs = dyn + 4 * kWideTile * S;
@@ -2829,6 +2879,9 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
         for (int vv = 0; vv < 4; ++vv) gb[vv] = gbn[vv];
     }
     FBSMI_STAMP(30)
+#ifdef FBSMI_STAMPS
+    if (threadIdx.x == 0 && s == d.T - 1) span[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // (Round 3 built the variant this file's history kept describing -- TWO independent accumulator chains per wave: 64-row G
@@ -4162,6 +4215,7 @@ int fbsmi_lg_sweep_view(fbsmi_lg_sweep* s, int which, void* dst, int64_t* count,
         case 6: src = d.vs; n = (int64_t)d.C * (d.T + 1) * d.dv; break;
         case 7: src = d.dbg; n = 128; break;  // 64 x uint64 as 32-bit words (diagnostic build)
         case 8: src = d.cdfJ; n = (int64_t)d.C * d.N; break;   // (diagnostic build: per-workgroup entry / exit stamps of the last step)
+        case 9: src = d.xiw ? d.xiw + (size_t)d.N * d.du : nullptr; n = 16384; break;   // (diagnostic build: the drift kernel's workgroups)
         default: return fail(FBSMI_ERR_ARG, "lg_sweep_view: unknown view");
     }
     if (!src) n = 0;

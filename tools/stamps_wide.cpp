@@ -36,7 +36,29 @@ int main(int argc, char** argv) {
         int fo[] = {20, 21, 22, 23, 24, 25, 26, 27, 30};
         double f0 = rt(20), fp = f0;
         for (int i : fo) { printf("%-44s t=%8.0f ns  (+%6.0f)\n", fn[i], rt(i) - f0, rt(i) - fp); fp = rt(i); }
-        printf("(d=100, N=%d, chains=%d; the last step of a sweep)\n", N, C);
+        {   // every workgroup's entry / exit (view 9)
+            const int nwg = ((N + 31) / 32) * C;
+            unsigned long long* dv; (void)hipMalloc(&dv, 16384 * 4);
+            fbsmi_lg_sweep_view(h, 9, dv, &cnt, st); (void)hipStreamSynchronize(st);
+            std::vector<unsigned long long> sp(8192);
+            (void)hipMemcpy(sp.data(), dv, 8192 * 8, hipMemcpyDeviceToHost);
+            if (nwg <= 4096) {
+                unsigned long long t0 = ~0ull, t1 = 0; double life = 0, lmax = 0, lmin = 1e18;
+                for (int w = 0; w < nwg; ++w) { t0 = sp[2 * w] < t0 ? sp[2 * w] : t0; t1 = sp[2 * w + 1] > t1 ? sp[2 * w + 1] : t1; }
+                int late = 0; unsigned long long lastin = 0;
+                for (int w = 0; w < nwg; ++w) {
+                    const double l = (double)(sp[2 * w + 1] - sp[2 * w]) * 10.0;
+                    life += l; lmax = l > lmax ? l : lmax; lmin = l < lmin ? l : lmin;
+                    if ((sp[2 * w] - t0) * 10 > 5000) ++late;
+                    lastin = sp[2 * w] > lastin ? sp[2 * w] : lastin;
+                }
+                printf("%d workgroups: first entry -> last exit %.0f ns; lifetimes %.0f .. %.0f ns (mean %.0f); last entry at +%.0f ns; %d entered more than 5 us after the first\n",
+                       nwg, (double)(t1 - t0) * 10.0, lmin, lmax, life / nwg, (double)(lastin - t0) * 10.0, late);
+            }
+        }
+        // shader-clock counter against the 100 MHz wall clock over the workgroup's lifetime: the clock the kernel really ran at
+        const double dsh = (double)(hh[2 * 30 + 1] - hh[2 * 20 + 1]), dwall = rt(30) - rt(20);
+        printf("(d=100, N=%d, chains=%d; the last step of a sweep; s_memtime / wall = %.3f ticks per ns)\n", N, C, dsh / dwall);
         return 0;
     }
     names[31] = "pre own draws done (row loads in flight)";
