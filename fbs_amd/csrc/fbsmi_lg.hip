@@ -99,6 +99,8 @@ struct LgDev {
     int32_t* anc;                           // [N] ancestors of the current step (wide path)
     float* xiw;                             // [2][N][du] a step's noise, drawn ahead of the launch that uses it (wide models): slot s & 1
                                             // for the one-tile Gibbs step (drawn DURING the previous launch), slot 0 for k_lgw_noise
+    float* uw;                              // [2][2][N] one-tile wide Gibbs step: the kill-test and redraw uniforms of every source slot
+                                            // (resamplings.py:71-74), drawn ahead like the noise: slot s & 1, u1 then u2 (nullable)
     int lh_w, lh_j;                         // their depths
     // two-launch step (N a power of two, 2..256 tiles): the searches walk the summation tree itself, so no cdf is written
     float2* trW;                            // [nb][64]: per tile, heap-ordered nodes (sum of the node's left half, w at its midpoint)
@@ -181,6 +183,7 @@ __device__ __forceinline__ LgDev chain_view(LgDev d, int c) {
         d.lpw += (size_t)((d.dv + 3) & ~3) * N * c;
         d.anc += N * c;
         d.xiw += 2 * N * du * c;
+        if (d.uw) d.uw += 4 * N * c;
     }
     if (d.hpW) {
         d.hpW += (size_t)kHeapSizeW * c;
@@ -539,6 +542,23 @@ __device__ __forceinline__ float tree_fold(float x, const float (&sib)[8], int l
 #pragma unroll
     for (int lv = 0; lv < 8; ++lv) x = lv < levels ? x + sib[lv] : x;
     return x;
+}
+
+// One-tile wide Gibbs step: the draws of step sn that do not depend on the step before it -- normal(key_transition, (N, du)) and the
+// two uniforms per source slot of the conditional killing resampler -- by producer block `blk` of `nblk` (idle blocks of a pinned
+// launch, extra blocks of an unpinned one, or every working block a share at its end), into slot sn & 1.
+__device__ __forceinline__ void wide_draw_ahead(const LgDev& d, int sn, int blk, int nblk) {
+    const uint32_t* kt = d.keytab + 8 * sn;
+    const uint32_t n0 = kt[6], n1 = kt[7];
+    const int total = d.N * d.du;
+    float* dst = d.xiw + (size_t)(sn & 1) * total;
+    for (int e = blk * kBlock + (int)threadIdx.x; e < total; e += nblk * kBlock) dst[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
+    if (d.uw) {   // (from the far end of the producers: the first ones hold the larger noise shares)
+        const uint32_t a0 = kt[0], a1 = kt[1], b0 = kt[2], b1 = kt[3];
+        float* du2 = d.uw + (size_t)(sn & 1) * 2 * d.N;
+        for (int e = (nblk - 1 - blk) * kBlock + (int)threadIdx.x; e < 2 * d.N; e += nblk * kBlock)
+            du2[e] = e < d.N ? uniform_at(a0, a1, (uint64_t)d.N, (uint64_t)e) : uniform_at(b0, b1, (uint64_t)d.N, (uint64_t)(e - d.N));
+    }
 }
 
 // One third (`part` of 3) of normal(key_transition, (N, du)) of step s into d.xiw, by the `nblk` extra blocks of a launch
@@ -2041,9 +2061,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_init(LgDev dd) {
         }
     }
     if (d.N <= kBlock) {   // one-tile ensembles take their noise from d.xiw: step 0's is drawn here (one workgroup: N <= 256)
-        const uint32_t n0 = d.keytab[6], n1 = d.keytab[7];
-        const int total = d.N * d.du;
-        for (int e = threadIdx.x; e < total; e += kBlock) d.xiw[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
+        wide_draw_ahead(d, 0, 0, 1);
     }
     const int p = p0 + threadIdx.x;
     float lv[1] = {-__builtin_inff()};
@@ -2203,8 +2221,16 @@ __device__ __forceinline__ void lgw_pre_body(const LgDev& d, int s, bool store, 
     __builtin_amdgcn_sched_barrier(0);
     early();
     const float u3 = __uint_as_float(kt[4]);
-    const float u1 = live ? uniform_at(a0, a1, (uint64_t)N, (uint64_t)t) : 0.0f;
-    const float u2 = live ? uniform_at(b0, b1, (uint64_t)N, (uint64_t)t) : 0.0f;
+    float u1 = 0.0f, u2 = 0.0f;
+    if (ROWS && d.uw) {   // drawn ahead by the previous launch (wide_draw_ahead): two loads instead of two Threefry calls
+        if (live) {
+            u1 = d.uw[(size_t)(s & 1) * 2 * N + t];
+            u2 = d.uw[(size_t)(s & 1) * 2 * N + N + t];
+        }
+    } else if (live) {
+        u1 = uniform_at(a0, a1, (uint64_t)N, (uint64_t)t);
+        u2 = uniform_at(b0, b1, (uint64_t)N, (uint64_t)t);
+    }
     FBSMI_STAMP(31)
     __builtin_amdgcn_sched_barrier(0);
     if (ROWS && live && (s || d.ef)) {
@@ -2370,12 +2396,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
         if (KIND == 1) {
             const LgDev dq = chain_view(dd, blockIdx.y);
             if (s + 1 < dq.T) {
-                const uint32_t n0 = dq.keytab[8 * (s + 1) + 6], n1 = dq.keytab[8 * (s + 1) + 7];
-                const int total = dq.N * dq.du;
                 const int r8 = (int)(blockIdx.x & 7), idle = bx * 7 + (r8 > pslot ? r8 - 1 : r8), nidle = gx * 7;
-                float* dst = dq.xiw + (size_t)((s + 1) & 1) * total;
-                for (int e = idle * kBlock + (int)threadIdx.x; e < total; e += nidle * kBlock)
-                    dst[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
+                wide_draw_ahead(dq, s + 1, idle, nidle);
             }
         }
         return;
@@ -2387,13 +2409,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     const int work = ((d.N + kWideTile - 1) / kWideTile) * nrt;   // working blocks of a launch that covers all row tiles
     const bool extra_noise = KIND == 1 && !pin && (int)gridDim.x > work;
     if (extra_noise && bx >= work) {
-        if (s + 1 < d.T) {
-            const uint32_t n0 = d.keytab[8 * (s + 1) + 6], n1 = d.keytab[8 * (s + 1) + 7];
-            const int total = d.N * d.du, nx = (int)gridDim.x - work;
-            float* dst = d.xiw + (size_t)((s + 1) & 1) * total;
-            for (int e = (bx - work) * kBlock + (int)threadIdx.x; e < total; e += nx * kBlock)
-                dst[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
-        }
+        if (s + 1 < d.T) wide_draw_ahead(d, s + 1, bx - work, (int)gridDim.x - work);
         return;
     }
     __shared__ LgwPreLds pre;
@@ -2556,13 +2572,29 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     {
         const float4* ga = reinterpret_cast<const float4*>(Gs + wide_pos(16 * ar + (lane & 15), lane >> 4, S));
         const float4* zb = reinterpret_cast<const float4*>(Zs + wide_pos(jloc, lane >> 4, S));
-#pragma unroll 2
-        for (int q4 = 0; q4 < (Q >> 2); ++q4) {
-            const float4 a = ga[q4], b = zb[q4];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+        // two operand sets in turn: the reads of the next four products are in flight under the current four (k_lgw_gemm_fat)
+        const int nq = Q >> 2;
+        float4 a0 = ga[0], b0 = zb[0];
+#pragma unroll 1
+        for (int q4 = 0; q4 < nq; q4 += 2) {
+            const int q1 = q4 + 1 < nq ? q4 + 1 : q4, q2 = q4 + 2 < nq ? q4 + 2 : q4;
+            const float4 a1 = ga[q1], b1 = zb[q1];
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q4 + 1 < nq) {
+                a0 = ga[q2];
+                b0 = zb[q2];
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     FBSMI_STAMP(23)
@@ -2622,12 +2654,14 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     const bool stamp_tail = false;
 #endif
     if (KIND == 1 && !pin && !extra_noise && (s + 1 < d.T || stamp_tail)) {   // this workgroup's share of the next step's noise (pinned
-        const int sn = s + 1 < d.T ? s + 1 : s;               // launches: the idle blocks on the other XCDs drew it)
-        const uint32_t n0 = d.keytab[8 * sn + 6], n1 = d.keytab[8 * sn + 7];
-        const int total = N * du, per = (total + gx - 1) / gx;
-        const int e0 = bx * per, e1 = e0 + per < total ? e0 + per : total;
-        float* dst = d.xiw + (size_t)((s + 1) & 1) * total;   // the other half: blocks of this launch may still be reading this step's
-        for (int e = e0 + t; e < e1; e += kBlock) dst[e] = normal_at(n0, n1, (uint64_t)total, (uint64_t)e);
+        // launches: the idle blocks on the other XCDs drew it).  Into the other half: blocks of this launch may still be reading
+        // this step's.  (Diagnostic build, last step: the draws of a step that does not exist, with step s's keys, timed only.)
+        if (s + 1 < d.T) wide_draw_ahead(d, s + 1, bx, gx);
+        else {
+            LgDev dx = d;
+            dx.keytab = d.keytab - 8;
+            wide_draw_ahead(dx, s + 1, bx, gx);
+        }
     }
     FBSMI_STAMP(24)
 }
@@ -3962,10 +3996,13 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
     rc |= slab_request(s, &d.bsumexp, C * d.nb);
     d.anc = nullptr;
     d.xiw = nullptr;
+    d.uw = nullptr;
     if (wide) {
         rc |= slab_request(s, &d.lpw, C * (size_t)((d.dv + 3) & ~3) * N);
         rc |= slab_request(s, &d.anc, C * N);
         rc |= slab_request(s, &d.xiw, 2 * C * N * d.du);
+        static const int upre = [] { const char* e = getenv("FBSMI_WIDE_UPRE"); return e ? atoi(e) : 1; }();
+        if (upre && N <= kBlock) rc |= slab_request(s, &d.uw, 4 * C * (size_t)N);
     }
     d.hpW = d.hpJ = nullptr;
     d.hp_map = nullptr;
