@@ -80,7 +80,7 @@ def gp100_leg(dev):
     br = fbs_amd.LinearGaussianBridge(np.zeros(2 * d), joint, StationaryConstLinearSDE(a=-0.5, b=1.), ts, d, device=dev)
     y0 = np.random.default_rng(0).normal(size=d).astype(np.float32)
     out = []
-    for N, nrep in ((100, 20), (10000, 5)):
+    for N, nrep in ((100, 20), (10000, 5), (100000, 3)):
         sw = br.sweep_handle(N, True, False, nchains=C)
         k, x, b, _ = sw.chain(fbs_amd.PRNGKey(1), np.zeros((C, d), np.float32), y0, np.zeros((C, T + 1), np.int32), 2,
                               keep=False)
@@ -94,10 +94,11 @@ def gp100_leg(dev):
                     "value": float(N) * T * C / dt, "unit": "particle-steps/s",
                     "drift_TFLOPs": tf, "frac_of_f32_mfma_peak": tf / 157.3})
         del sw
+        torch.cuda.empty_cache()
     return {"workload": "gp_gibbs.py --d=100 --explicit_backward (toy_gibbs.sh), 4 chains; nparticles=100 is the paper's "
-                        "table (tabulate_toy.py:16), 10000 shows the drift kernel loaded", "runs": out,
-            "note": "f32 MFMA (exact fmaf chain) dense peak 157.3 TFLOP/s; at nparticles=100 a step is two launches "
-                    "and latency-bound"}
+                        "table (tabulate_toy.py:16), 10000 and 100000 show the drift kernel loaded", "runs": out,
+            "note": "f32 MFMA (exact fmaf chain) dense peak 157.3 TFLOP/s; at nparticles=100 a step is one launch "
+                    "and latency-bound; from 10000 particles up a step is five launches around k_lgw_gemm_fat"}
 
 
 def image_legs(dev, nsteps, dtypes=("f32", "bf16")):
