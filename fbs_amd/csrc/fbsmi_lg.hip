@@ -2574,8 +2574,9 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     {
         const float4* ga = reinterpret_cast<const float4*>(Gs + wide_pos(16 * ar + (lane & 15), lane >> 4, S));
         const float4* zb = reinterpret_cast<const float4*>(Zs + wide_pos(jloc, lane >> 4, S));
-        // two operand sets in turn: the reads of the next four products are in flight under the current four (k_lgw_gemm_fat)
-        const int nq = Q >> 2;
+        // two operand sets in turn: the reads of the next four products are in flight under the current four (k_lgw_gemm_fat);
+        // waves whose sixteen rows lie wholly outside the matrix have nothing to multiply
+        const int nq = kWideTile * tr + 16 * ar < D ? Q >> 2 : 0;
         float4 a0 = ga[0], b0 = zb[0];
 #pragma unroll 1
         for (int q4 = 0; q4 < nq; q4 += 2) {
@@ -2695,6 +2696,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_noise(LgDev dd, int s) {
 // workgroup either way, i.e. the CU is saturated by two: per row tile a wave issues ~290 vector instructions besides its 52
 // dependent products, and the two kinds overlap little.  Starting the workgroups of a CU out of phase (s_sleep by b / 256) made
 // it slower.)
+template <bool VEC4>   // D and du multiples of four: rows are whole float4s (the usual case; the other is kept for odd sizes)
 __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nrt, int Kp, int S) {
     const LgDev d = chain_view(dd, blockIdx.y);
 #ifdef FBSMI_STAMPS
@@ -2721,7 +2723,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     const float* ustar = d.us_star + (size_t)(s + 1) * du;
     FBSMI_STAMP(20)
     constexpr int kRows = kWideTile / kWaves;
-    const bool vec4 = (D & 3) == 0 && (du & 3) == 0;
+    constexpr bool vec4 = VEC4;
     const int Q = Kp >> 2;
     int an[kRows];
 #pragma unroll
@@ -2835,8 +2837,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
         // the operands of the NEXT four products travel from LDS while the current four (a dependent chain, 4 x 8 passes) run:
         // two operand sets in turn, the scheduling barriers keep each read in front of the products it overlaps (left alone the
         // compiler rotates the read to the top of the next iteration and waits for it there)
-        {
-            const int nq = Q >> 2;
+        if (kWideTile * tr + 16 * ar < D) {   // (the upper half of the last row tile can lie wholly outside the matrix: D = 200 ends
+            const int nq = Q >> 2;            // at row 8 of tile 6, whose waves with ar = 1 have nothing to multiply)
             float4 a0 = ga[0], b0 = zb[0];
 #pragma unroll 1
             for (int q4 = 0; q4 < nq; q4 += 2) {
@@ -3806,7 +3808,10 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                     if (!fold)
                         k_lgw_noise<<<dim3((unsigned)((pairs + kBlock - 1) / kBlock < 4096 ? (pairs + kBlock - 1) / kBlock : 4096), d.C),
                                       kBlock, 0, st>>>(d, k);
-                    k_lgw_gemm_fat<<<dim3((d.N + kWideTile - 1) / kWideTile, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+                    if ((d.D & 3) == 0 && (d.du & 3) == 0)
+                        k_lgw_gemm_fat<true><<<dim3((d.N + kWideTile - 1) / kWideTile, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+                    else
+                        k_lgw_gemm_fat<false><<<dim3((d.N + kWideTile - 1) / kWideTile, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
                 }
                 else
                     k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
@@ -4096,7 +4101,8 @@ int fbsmi_lg_sweep_create(const fbsmi_lg_model* m, int32_t nparticles, int expli
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm_fat, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm_fat<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_lgw_gemm_fat<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             fbsmi_lg_sweep_destroy(s);
             return fail(FBSMI_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
