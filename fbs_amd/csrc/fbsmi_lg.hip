@@ -2420,7 +2420,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm(LgDev dd, int s, int tr0, i
     float* Zs = dyn + 4 * kWideTile * S;    // [32 slots][S]: z = (u[ancestor], v_prev)
     const int N = d.N, du = d.du, D = d.D;
     const int ts = bx / nrt, tr = tr0 + (bx - ts * nrt);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // (the wave index as a SCALAR: row numbers, LDS rows and the half-tile tests that hang on it then live on the scalar unit)
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t* kt = d.keytab + 8 * s;
     const uint32_t t0 = kt[FILT ? 0 : 6], t1 = kt[FILT ? 1 : 7];   // key_transition (Gibbs) / key_proposal (filters)
     const int j_ref = FILT ? -1 : d.bs[s + 1];
@@ -2710,7 +2711,8 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     float* Zs = dyn + 4 * kWideTile * S;
     const int N = d.N, du = d.du, D = d.D;
     const int ts = blockIdx.x;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // (the wave index as a SCALAR: row numbers, LDS rows and the half-tile tests that hang on it then live on the scalar unit)
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int j_ref = d.bs[s + 1];
     const float* __restrict__ up = (s & 1) ? d.u1 : d.u0;
     float* __restrict__ un = (s & 1) ? d.u0 : d.u1;
