@@ -261,6 +261,14 @@ class LGSweep:
                 ((4 if (wide and self.C % 4 == 0 and nparticles >= 32768) else 2) if self.C >= 4 else 1)
             if G < 1 or self.C % G:
                 G = 1
+        sizes = os.environ.get("FBSMI_CHAIN_GROUP_SIZES") if _group is None else None   # (diagnostic: uneven groups, e.g. "2,1,1")
+        if sizes:
+            sz = [int(x) for x in sizes.split(",")]
+            if sum(sz) == self.C and all(x > 0 for x in sz) and len(sz) > 1:
+                first = np.cumsum([0] + sz[:-1])
+                self.children = [LGSweep(model, nparticles, eb, ef, store, n, _group=(self.C, int(f))) for n, f in zip(sz, first)]
+                self._harr = (C.c_void_p * len(sz))(*[c.h for c in self.children])
+                return
         if G > 1:
             per = self.C // G
             self.children = [LGSweep(model, nparticles, eb, ef, store, per, _group=(self.C, g * per)) for g in range(G)]

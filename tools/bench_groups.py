@@ -37,7 +37,7 @@ def main():
                                       StationaryConstLinearSDE(a=-0.5, b=1.0), ts, du=1, device=dev)
     y0 = torch.zeros(1, device=dev)
     print(f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}  chains={Cn}  N={N}  T={T}")
-    for G in [g for g in (1, 2, 4, 8) if Cn % g == 0 and g <= Cn]:
+    for G in [g for g in (1, 2, 3, 4, 6, 8) if Cn % g == 0 and g <= Cn]:
         os.environ["FBSMI_CHAIN_GROUPS"] = str(G)
         sw = fbs_amd.linear_gaussian.LGSweep(br, N, True, False, False, Cn)
         kt = torch.from_numpy(np.asarray(ops.PRNGKey(5)).astype(np.uint32).view(np.int32).copy()).to(dev).reshape(1, 2)
