@@ -4225,6 +4225,11 @@ int fbsmi_lg_gibbs_chain_groups(fbsmi_lg_sweep* const* groups, int32_t ngroups, 
         expect += s->d.C;
     }
     if (expect != groups[0]->d.Ctot) return fail(FBSMI_ERR_ARG, "lg_gibbs_chain_groups: the handles do not cover the batch");
+    // group g runs on pool stream g (set_group's first_chain / C is the same number for groups of equal size; groups of unequal
+    // sizes could collide on it).  Only before a handle's graph exists: a captured graph replays on the stream it was captured on.
+    for (int g = 0; g < ngroups; ++g)
+        if (!groups[g]->graph_chain)
+            if (hipStream_t st = pool_stream(g)) groups[g]->stream = st;
     for (int g = 0; g < ngroups; ++g) {
         fbsmi_lg_sweep* s = groups[g];
         const size_t c0 = s->d.c0;

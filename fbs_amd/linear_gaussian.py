@@ -248,31 +248,36 @@ class LGSweep:
         # A batch of four or more chains is driven as two handles of half the chains each, on their own streams: the step
         # kernels are latency-bound, so the two halves' launches interleave and finish sooner than one full-size batch
         # (same results bit for bit; FBSMI_CHAIN_GROUPS=1 keeps one handle, =k asks for k groups).
-        G = 1
+        sz = None
         if _group is None:
-            # Two groups, except very large wide ensembles (launches of hundreds of microseconds), which take four.  Four
-            # streams of shorter dependent launches are pathological on some boxes: round 3 measured 28-31 us per step with
-            # four groups of one chain against 16 with two, for the narrow toy and for the d = 100 toy at 100 particles alike
-            # (round 2's box had run the latter 10 % faster with four), and d = 100 at 10 000 particles anywhere between 17
-            # and 28 ms per sweep with four groups against a steady 19-21 with two; at 100 000 particles four groups won on
-            # every box (152 against 174 ms).  The host is not the limit (0.3 us per graph node); the queues are.
+            # Two groups from four chains, three from five (narrow models), except very large wide ensembles (launches of hundreds
+            # of microseconds), which take four.  A FOURTH concurrent graph stream of short dependent launches is pathological
+            # (round 3: 28-31 us per step with four groups of one chain against 16-17 with two or three groups, for the narrow toy
+            # and for the d = 100 toy at 100 particles alike; d = 100 at 10 000 particles anywhere between 17 and 28 ms per sweep
+            # with four groups against a steady 19-21 with two; at 100 000 particles four groups won on every box, 152 against
+            # 174 ms), three are not: config 2's model with 8 chains as (3, 3, 2) 22.3 us per step against 23.9 as (4, 4), 16
+            # chains as (6, 5, 5) 29.8 against 31.6, 5 chains as (2, 2, 1) 17.9 against 18.6 as (3, 2); at the reference's four
+            # chains (2, 2) and (2, 1, 1) measure the same.  The host is not the limit (0.3 us per graph node); the queues are.
+            # FBSMI_CHAIN_GROUPS=1 keeps one handle, =k asks for k groups, FBSMI_CHAIN_GROUP_SIZES=a,b,.. for explicit sizes.
             wide = max(model.du, model.dv) > 16
-            G = int(os.environ.get("FBSMI_CHAIN_GROUPS", "0")) or \
-                ((4 if (wide and self.C % 4 == 0 and nparticles >= 32768) else 2) if self.C >= 4 else 1)
-            if G < 1 or self.C % G:
-                G = 1
-        sizes = os.environ.get("FBSMI_CHAIN_GROUP_SIZES") if _group is None else None   # (diagnostic: uneven groups, e.g. "2,1,1")
-        if sizes:
-            sz = [int(x) for x in sizes.split(",")]
-            if sum(sz) == self.C and all(x > 0 for x in sz) and len(sz) > 1:
-                first = np.cumsum([0] + sz[:-1])
-                self.children = [LGSweep(model, nparticles, eb, ef, store, n, _group=(self.C, int(f))) for n, f in zip(sz, first)]
-                self._harr = (C.c_void_p * len(sz))(*[c.h for c in self.children])
-                return
-        if G > 1:
-            per = self.C // G
-            self.children = [LGSweep(model, nparticles, eb, ef, store, per, _group=(self.C, g * per)) for g in range(G)]
-            self._harr = (C.c_void_p * G)(*[c.h for c in self.children])
+            sizes = os.environ.get("FBSMI_CHAIN_GROUP_SIZES")
+            if sizes:
+                sz = [int(x) for x in sizes.split(",")]
+                if sum(sz) != self.C or any(x < 1 for x in sz):
+                    raise ValueError(f"FBSMI_CHAIN_GROUP_SIZES={sizes} does not cover {self.C} chains")
+            else:
+                G = int(os.environ.get("FBSMI_CHAIN_GROUPS", "0"))
+                if G < 1:
+                    if wide:
+                        G = (4 if (self.C % 4 == 0 and nparticles >= 32768) else 2) if self.C >= 4 else 1
+                    else:
+                        G = 3 if self.C >= 5 else (2 if self.C >= 4 else 1)
+                G = min(G, self.C)
+                sz = [self.C // G + (1 if g < self.C % G else 0) for g in range(G)]
+        if sz is not None and len(sz) > 1:
+            first = np.cumsum([0] + sz[:-1])
+            self.children = [LGSweep(model, nparticles, eb, ef, store, n, _group=(self.C, int(f))) for n, f in zip(sz, first)]
+            self._harr = (C.c_void_p * len(sz))(*[c.h for c in self.children])
             return
         h = C.c_void_p()
         with torch.cuda.device(model.device):

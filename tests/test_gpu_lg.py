@@ -306,9 +306,10 @@ def test_chain_and_closed_form_posterior(oracle, dev):
     np.testing.assert_allclose(xs.var(), 1.68, rtol=2e-2)       # test_gibbs.py:123
 
 
-@pytest.mark.parametrize("toy,C,N,T", [(toy_2d, 4, 100, 30), (toy_4d, 3, 300, 12), (toy_2d, 2, 1024, 20)])
+@pytest.mark.parametrize("toy,C,N,T", [(toy_2d, 4, 100, 30), (toy_4d, 3, 300, 12), (toy_2d, 2, 1024, 20),
+                                       (toy_2d, 5, 300, 12), (toy_4d, 7, 512, 8)])   # five and more chains: three groups of unequal sizes
 def test_batched_chains_match_oracle(toy, C, N, T, oracle, dev):
-    """nchains > 1: the reference's jax.vmap over chains (gp_gibbs.py:172-187), one launch sequence."""
+    """nchains > 1: the reference's jax.vmap over chains (gp_gibbs.py:172-187), one launch sequence (per chain group)."""
     toy = toy()
     ts = np.linspace(0, 1, T + 1)
     br = _bridge(toy, ts, dev)
