@@ -262,6 +262,7 @@ def sharded_leg(dev, dist, world, rank, nsteps):
             dist.barrier()
         dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
         net_ms = image_configs.network_ms(c)
+        sh.close()
         note(rank, f"sharded_c5 {exchange}: {dt / nsteps * 1e3:.1f} ms per step")
         res[exchange] = {"value": float(N) * nsteps / dt, "unit": "particle-steps/s", "ms_per_step": dt / nsteps * 1e3,
                          "network_ms_per_step_rank0": net_ms / nsteps, "rows_per_rank": sh.n,
@@ -312,10 +313,12 @@ def sharded_lg_leg(dev, dist, world, rank, nsteps):
                 dist.barrier()
             dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
             diag = sh.diagnostics.cpu().numpy()
+            moved = sh.bytes_moved
+            sh.close()
             note(rank, f"sharded_lg {name} {exchange}: {dt / nsteps * 1e3:.2f} ms per step")
             return {"value": float(N) * nsteps / dt, "unit": "particle-steps/s", "ms_per_step": dt / nsteps * 1e3,
                     "nparticles": N, "du": du, "rows_per_rank": sh.n, "exchange": sh.exchange_for(torch.empty(1, du)),
-                    "ancestor_exchange_bytes_received_per_step_rank0": sh.bytes_moved / nsteps,
+                    "ancestor_exchange_bytes_received_per_step_rank0": moved / nsteps,
                     "logweight_all_gather_bytes_per_step": 4 * (sh.world - 1) * sh.n,
                     "ess_last_step": float(diag[-1, 1]), "log_normaliser_sum": float(diag[:, 0].sum()),
                     "x0_checksum": float(res[0].double().sum().item())}

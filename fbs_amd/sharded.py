@@ -117,14 +117,21 @@ class DistContext:
         self.window_row = 0
 
     def close(self):
+        """Release the context.  COLLECTIVE when peer windows are open on more than one rank: every rank must call it (a
+        barrier makes sure nobody still reads the window this rank is about to free)."""
         if getattr(self, "_h", None) is not None and self._h.value:
             torch.cuda.synchronize(self.device)
+            if self.window_row and self.world > 1:
+                self.dist.barrier(group=self.group)
             self._lib.dist_lib().fbsmi_dist_destroy(self._h)
             self._h = None
 
     def __del__(self):
+        # Garbage collection is not collective: a context whose window peers may still be reading is left to the process's end
+        # rather than freed under them (call close() on every rank to release it earlier).
         try:
-            self.close()
+            if not (self.window_row and self.world > 1):
+                self.close()
         except Exception:
             pass
 
@@ -263,6 +270,12 @@ class ParticleShards:
     @bytes_moved.setter
     def bytes_moved(self, v: int):
         self._bytes_moved, self._remote_acc = int(v), None
+
+    def close(self):
+        """Release libfbsmi_dist's context (windows, communicator).  Collective on more than one rank with exchange="peer"."""
+        if self.native is not None:
+            self.native.close()
+            self.native = None
 
     def publish(self, us_local: torch.Tensor):
         """exchange="peer": this rank's rows of the step, into its window (before the step's log-weight collective)."""

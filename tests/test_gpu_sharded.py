@@ -67,6 +67,7 @@ def _worker(rank, world, port, q):
                                            sb.transition_logpdf, sb.likelihood_logpdf, sh, explicit_final=ef, mask_=mask)
                 same = all(torch.equal(a, b) for a, b in zip(got, want))
                 ok = ok and same and sh.bytes_moved > 0
+                sh.close()                                           # (collective for "peer": nobody reads a freed window)
         # ---- the linear-Gaussian closures (fbsmi_lg_transition_sampler_rows: the noise a row slice of the global draw) on a
         # sharded ensemble against the fused single-GPU sweep engine, for a narrow model and for a wide (d = 24) one
         import fbs_amd
@@ -91,6 +92,7 @@ def _worker(rank, world, port, q):
                 okd = dg is not None and tuple(dg.shape) == (T2 + 1, 2) and bool(torch.isfinite(dg).all()) and \
                     bool((dg[:, 1] >= 1.0 - 1e-4).all()) and bool((dg[:, 1] <= N + 1e-2).all())
                 ok = ok and same and okd
+                sh.close()
         dist.barrier()
         q.put((rank, bool(ok), ""))
     except Exception as e:  # report instead of hanging the other ranks' collectives forever
