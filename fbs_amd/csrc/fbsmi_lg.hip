@@ -2114,6 +2114,22 @@ __device__ __forceinline__ float lgw_row_sum(const LgDev& d, int m) {
     return lgw_row_add(d, L);
 }
 
+// the same sum with four loads in flight instead of all of them (16 registers instead of 128: for the tail of the drift kernel)
+__device__ __forceinline__ float lgw_row_sum_lean(const LgDev& d, int m) {
+    const int dvp = (d.dv + 3) & ~3, nq = dvp >> 2;
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(d.lpw + (size_t)m * dvp);
+    float a = 0.0f;
+#pragma unroll 4
+    for (int q = 0; q < nq; ++q) {
+        const float4 x = p[q];
+        a = q == 0 ? x.x : a + x.x;          // (the sum STARTS with the first term: 0 + x would lose the sign of a -0.0)
+        if (4 * q + 1 < d.dv) a = a + x.y;
+        if (4 * q + 2 < d.dv) a = a + x.z;
+        if (4 * q + 3 < d.dv) a = a + x.w;
+    }
+    return a;
+}
+
 // log-weights from the per-row terms, then the logsumexp tile partials (N > 256, and once after the
 // last step for the final-mode kernels)
 __global__ void __launch_bounds__(kBlock) k_lgw_lse(LgDev dd) {
@@ -2698,7 +2714,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_noise(LgDev dd, int s) {
 // dependent products, and the two kinds overlap little.  Starting the workgroups of a CU out of phase (s_sleep by b / 256) made
 // it slower.)
 template <bool VEC4>   // D and du multiples of four: rows are whole float4s (the usual case; the other is kept for odd sizes)
-__global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nrt, int Kp, int S) {
+__global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nrt, int Kp, int S, int rowsum) {
     const LgDev d = chain_view(dd, blockIdx.y);
 #ifdef FBSMI_STAMPS
     // diagnostic build: every workgroup of the last step's launch records its entry / exit time (view 9; the second noise slot of
@@ -2919,6 +2935,24 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
         for (int vv = 0; vv < 4; ++vv) gb[vv] = gbn[vv];
     }
     FBSMI_STAMP(30)
+    // The log-weights of this workgroup's slots: every row tile of a slot was written here, so its row sum (the reference's sum
+    // over the observation coordinates, in row order) can be taken here too, by one thread per slot reading back what the
+    // workgroup stored -- the launch that used to do it (k_lgw_lse: 8.5 us at 10 000 particles, uncoalesced rows of 416 bytes)
+    // shrinks to the logsumexp partials of 40 KB of log-weights (k_lg_lwpart).  Only for launches of a single round of
+    // workgroups (`rowsum`): in a long launch the tail keeps a workgroup's LDS for another microsecond while the next one waits
+    // for it (100 000 particles: 127 -> 145 ms per sweep with the tail, against 16.9 -> 16.5 ms at 10 000).
+    // (Hand-off inside one CU: every wave waits until its stores have been acknowledged by the L2, the barrier, then the reading
+    // wave drops this CU's L1 -- rows are 4 dvp bytes, not whole cache lines, so a neighbouring workgroup on this CU may have
+    // cached the line one of our rows ends in before we wrote it.)
+    if (rowsum) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t < kWideTile) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int m = kWideTile * ts + t;
+            if (m < N) d.lw[m] = lgw_row_sum_lean(d, m);
+        }
+    }
 #ifdef FBSMI_STAMPS
     if (threadIdx.x == 0 && s == d.T - 1) span[1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -3805,19 +3839,23 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
             ProfScope p(s, 2, st);
             if (d.wide) {
                 k_lgw_anc<<<gz, kBlock, 0, st>>>(dz, k);
+                bool fat_rowsum = false;
                 if (fat) {
                     const int64_t pairs = ((int64_t)d.N * d.du + 1) / 2;
                     if (!fold)
                         k_lgw_noise<<<dim3((unsigned)((pairs + kBlock - 1) / kBlock < 4096 ? (pairs + kBlock - 1) / kBlock : 4096), d.C),
                                       kBlock, 0, st>>>(d, k);
+                    const int nst = (d.N + kWideTile - 1) / kWideTile;
+                    fat_rowsum = (int64_t)nst * d.C <= 3 * 256;   // one round of workgroups (three per CU): row sums in the kernel's tail
                     if ((d.D & 3) == 0 && (d.du & 3) == 0)
-                        k_lgw_gemm_fat<true><<<dim3((d.N + kWideTile - 1) / kWideTile, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+                        k_lgw_gemm_fat<true><<<dim3(nst, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S, fat_rowsum ? 1 : 0);
                     else
-                        k_lgw_gemm_fat<false><<<dim3((d.N + kWideTile - 1) / kWideTile, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
+                        k_lgw_gemm_fat<false><<<dim3(nst, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S, fat_rowsum ? 1 : 0);
                 }
                 else
                     k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
-                k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
+                if (fat_rowsum) k_lg_lwpart<<<gtile, kBlock, 0, st>>>(d);   // the drift kernel left the row sums in d.lw
+                else k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
             } else if (tree && two_slot && !d.plus1) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2t<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
             } else if (tree && !d.plus1 && nb % 4 == 0 && (s->tree_halves == 4 || (s->tree_halves < 0 && (int64_t)nb * d.C >= 4 * 256))) {
