@@ -2940,7 +2940,10 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     // workgroup stored -- the launch that used to do it (k_lgw_lse: 8.5 us at 10 000 particles, uncoalesced rows of 416 bytes)
     // shrinks to the logsumexp partials of 40 KB of log-weights (k_lg_lwpart).  Only for launches of a single round of
     // workgroups (`rowsum`): in a long launch the tail keeps a workgroup's LDS for another microsecond while the next one waits
-    // for it (100 000 particles: 127 -> 145 ms per sweep with the tail, against 16.9 -> 16.5 ms at 10 000).
+    // for it (100 000 particles: 127 -> 145 ms per sweep with the tail, against 16.9 -> 16.5 ms at 10 000).  (Also built and
+    // dropped: the tile partials here as well, by the last of a tile's eight workgroups -- write-through log-weights, an arrival
+    // counter, one agent-scope acquire; bit-exact, one launch fewer, and 16.30 against 16.35 ms: the fence and the two extra
+    // barriers in every workgroup's tail cost what the launch did.)
     // (Hand-off inside one CU: every wave waits until its stores have been acknowledged by the L2, the barrier, then the reading
     // wave drops this CU's L1 -- rows are 4 dvp bytes, not whole cache lines, so a neighbouring workgroup on this CU may have
     // cached the line one of our rows ends in before we wrote it.)
