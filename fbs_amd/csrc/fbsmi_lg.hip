@@ -2114,22 +2114,6 @@ __device__ __forceinline__ float lgw_row_sum(const LgDev& d, int m) {
     return lgw_row_add(d, L);
 }
 
-// the same sum with four loads in flight instead of all of them (16 registers instead of 128: for the tail of the drift kernel)
-__device__ __forceinline__ float lgw_row_sum_lean(const LgDev& d, int m) {
-    const int dvp = (d.dv + 3) & ~3, nq = dvp >> 2;
-    const float4* __restrict__ p = reinterpret_cast<const float4*>(d.lpw + (size_t)m * dvp);
-    float a = 0.0f;
-#pragma unroll 4
-    for (int q = 0; q < nq; ++q) {
-        const float4 x = p[q];
-        a = q == 0 ? x.x : a + x.x;          // (the sum STARTS with the first term: 0 + x would lose the sign of a -0.0)
-        if (4 * q + 1 < d.dv) a = a + x.y;
-        if (4 * q + 2 < d.dv) a = a + x.z;
-        if (4 * q + 3 < d.dv) a = a + x.w;
-    }
-    return a;
-}
-
 // log-weights from the per-row terms, then the logsumexp tile partials (N > 256, and once after the
 // last step for the final-mode kernels)
 __global__ void __launch_bounds__(kBlock) k_lgw_lse(LgDev dd) {
@@ -2714,7 +2698,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_noise(LgDev dd, int s) {
 // dependent products, and the two kinds overlap little.  Starting the workgroups of a CU out of phase (s_sleep by b / 256) made
 // it slower.)
 template <bool VEC4>   // D and du multiples of four: rows are whole float4s (the usual case; the other is kept for odd sizes)
-__global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nrt, int Kp, int S, int rowsum) {
+__global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nrt, int Kp, int S) {
     const LgDev d = chain_view(dd, blockIdx.y);
 #ifdef FBSMI_STAMPS
     // diagnostic build: every workgroup of the last step's launch records its entry / exit time (view 9; the second noise slot of
@@ -2824,6 +2808,15 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
     // values g[r] used to be loaded after the next G tile had been asked for, and the products started only when that whole
     // prefetch had arrived (half of the kernel's wave-cycles were such waits).  Now the bias of tile tr + 1 is fetched one tile
     // ahead, and within a tile the loads go out in the order of their use: next bias, this tile's noise, next G tile.
+    // float4 path: a lane keeps the log-density terms of its rows >= du (four per row tile, at most five such tiles: dv <= 128)
+    // in registers until the tiles are done with the LDS; they never travel through global memory (below)
+    constexpr int kVTiles = 5;
+    const int vt0 = du / kWideTile;   // first row tile that holds rows >= du
+    float vsv[kVTiles][4];
+#pragma unroll
+    for (int j = 0; j < kVTiles; ++j)
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) vsv[j][vv] = 0.0f;
     float gb[4];
 #pragma unroll
     for (int vv = 0; vv < 4; ++vv) {
@@ -2904,7 +2897,13 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
                 float l4[4];
 #pragma unroll
                 for (int vv = 0; vv < 4; ++vv) l4[vv] = norm_logpdf(tg[vv], pv[vv] + acc[vv] * d.dt, sd2, lognorm);
-                *reinterpret_cast<float4*>(d.lpw + (size_t)mo * dvp + rv0) = make_float4(l4[0], l4[1], l4[2], l4[3]);
+                const int jt = tr - vt0;   // (uniform: a scalar branch per candidate, no indexed registers)
+#pragma unroll
+                for (int j = 0; j < kVTiles; ++j)
+                    if (jt == j) {
+#pragma unroll
+                        for (int vv = 0; vv < 4; ++vv) vsv[j][vv] = l4[vv];
+                    }
             }
         } else if (mo < N) {
 #pragma unroll
@@ -2935,25 +2934,38 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
         for (int vv = 0; vv < 4; ++vv) gb[vv] = gbn[vv];
     }
     FBSMI_STAMP(30)
-    // The log-weights of this workgroup's slots: every row tile of a slot was written here, so its row sum (the reference's sum
-    // over the observation coordinates, in row order) can be taken here too, by one thread per slot reading back what the
-    // workgroup stored -- the launch that used to do it (k_lgw_lse: 8.5 us at 10 000 particles, uncoalesced rows of 416 bytes)
-    // shrinks to the logsumexp partials of 40 KB of log-weights (k_lg_lwpart).  Only for launches of a single round of
-    // workgroups (`rowsum`): in a long launch the tail keeps a workgroup's LDS for another microsecond while the next one waits
-    // for it (100 000 particles: 127 -> 145 ms per sweep with the tail, against 16.9 -> 16.5 ms at 10 000).  (Also built and
-    // dropped: the tile partials here as well, by the last of a tile's eight workgroups -- write-through log-weights, an arrival
-    // counter, one agent-scope acquire; bit-exact, one launch fewer, and 16.30 against 16.35 ms: the fence and the two extra
-    // barriers in every workgroup's tail cost what the launch did.)
-    // (Hand-off inside one CU: every wave waits until its stores have been acknowledged by the L2, the barrier, then the reading
-    // wave drops this CU's L1 -- rows are 4 dvp bytes, not whole cache lines, so a neighbouring workgroup on this CU may have
-    // cached the line one of our rows ends in before we wrote it.)
-    if (rowsum) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The log-weights of this workgroup's slots.  Every row tile of a slot was multiplied here, so the slot's row sum (the
+    // reference's sum over the observation coordinates, in row order) is taken here too: once the tiles are done with the LDS
+    // the lanes park their terms in the G tile's memory as [32 slots][dv + 4] (rows 27 quads apart at d = 100: conflict-free for
+    // the 32 readers), and one thread per slot adds its row in order.  The terms never reach global memory and the launch that
+    // read them back (k_lgw_lse: 8.5 us at 10 000 particles, 4 MB per chain in uncoalesced 416-byte rows) becomes k_lg_lwpart,
+    // the logsumexp partials of the log-weights.  (An earlier form read the rows back from global memory in this tail --
+    // stores drained, the CU's L1 dropped: 6 us per workgroup, affordable only in single-round launches.)
+    if (VEC4) {
+        float* Ls = dyn;
+        const int LSs = dvp + 4;
+        __syncthreads();   // every wave is done with the tiles
+#pragma unroll
+        for (int j = 0; j < kVTiles; ++j) {
+            const int r0 = kWideTile * (vt0 + j) + 16 * ar + 4 * (lane >> 4);
+            if (r0 >= du && r0 < D)
+                *reinterpret_cast<float4*>(Ls + jloc * LSs + (r0 - du)) = make_float4(vsv[j][0], vsv[j][1], vsv[j][2], vsv[j][3]);
+        }
         __syncthreads();
         if (t < kWideTile) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const int m = kWideTile * ts + t;
-            if (m < N) d.lw[m] = lgw_row_sum_lean(d, m);
+            if (m < N) {
+                const float4* p = reinterpret_cast<const float4*>(Ls + t * LSs);
+                float a = 0.0f;
+                for (int q = 0; q < (d.dv >> 2); ++q) {   // dv is a multiple of four on this path
+                    const float4 x = p[q];
+                    a = q == 0 ? x.x : a + x.x;          // (the sum STARTS with the first term: 0 + x would lose the sign of a -0.0)
+                    a = a + x.y;
+                    a = a + x.z;
+                    a = a + x.w;
+                }
+                d.lw[m] = a;
+            }
         }
     }
 #ifdef FBSMI_STAMPS
@@ -3849,15 +3861,15 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
                         k_lgw_noise<<<dim3((unsigned)((pairs + kBlock - 1) / kBlock < 4096 ? (pairs + kBlock - 1) / kBlock : 4096), d.C),
                                       kBlock, 0, st>>>(d, k);
                     const int nst = (d.N + kWideTile - 1) / kWideTile;
-                    fat_rowsum = (int64_t)nst * d.C <= 3 * 256;   // one round of workgroups (three per CU): row sums in the kernel's tail
-                    if ((d.D & 3) == 0 && (d.du & 3) == 0)
-                        k_lgw_gemm_fat<true><<<dim3(nst, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S, fat_rowsum ? 1 : 0);
+                    fat_rowsum = (d.D & 3) == 0 && (d.du & 3) == 0;   // the float4 kernel leaves the log-weights in d.lw
+                    if (fat_rowsum)
+                        k_lgw_gemm_fat<true><<<dim3(nst, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
                     else
-                        k_lgw_gemm_fat<false><<<dim3(nst, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S, fat_rowsum ? 1 : 0);
+                        k_lgw_gemm_fat<false><<<dim3(nst, d.C), kBlock, w_lds, st>>>(d, k, w_nrt, w_Kp, w_S);
                 }
                 else
                     k_lgw_gemm<0><<<gwide, kBlock, w_lds, st>>>(d, k, 0, w_nrt, w_Kp, w_S, 3, 0);
-                if (fat_rowsum) k_lg_lwpart<<<gtile, kBlock, 0, st>>>(d);   // the drift kernel left the row sums in d.lw
+                if (fat_rowsum) k_lg_lwpart<<<gtile, kBlock, 0, st>>>(d);   // tile partials of the log-weights the drift kernel left
                 else k_lgw_lse<<<gtile, kBlock, 0, st>>>(d);
             } else if (tree && two_slot && !d.plus1) {
                 LG_DISPATCH(s, (void)ITEMS; (k_lg_prop2t<DMAX><<<dim3(nb / 2, d.C), kBlock, 0, st>>>(d, k)));
