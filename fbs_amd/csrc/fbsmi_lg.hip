@@ -3829,7 +3829,11 @@ int enqueue_sweep(fbsmi_lg_sweep* s, hipStream_t st, int chain) {
     // Large wide ensembles (the fat drift kernel): the step's noise is drawn by extra blocks of the three small launches in front
     // of the drift kernel -- norm, cdf and the ancestor search need a few dozen workgroups each and leave the chip empty --
     // instead of a launch of its own (k_lgw_noise: ~10 us per step at 10 000 particles).  FBSMI_WIDE_NOISE_FOLD=0: the own launch.
-    const bool fat = d.wide && (int64_t)gwide.x * d.C > 2048;   // enough workgroups to fill the chip twice over: gather once per slot tile
+    // The fat kernel (one workgroup per slot tile walks all row tiles: the gather once per slot tile, noise by the small
+    // launches, row sums in its tail, no k_lgw_lse) from ~700 tiled workgroups per launch: d = 100, 4 chains in two groups:
+    // 2000 particles 8.6 against 9.3 ms per sweep, 4000: 9.2 against 11.4; 1000: 8.4 against 7.8 (FBSMI_FAT_MIN moves it).
+    static const int fat_min = [] { const char* e = getenv("FBSMI_FAT_MIN"); return e ? atoi(e) : 700; }();
+    const bool fat = d.wide && (int64_t)gwide.x * d.C > fat_min;
     static const int noise_fold = [] { const char* e = getenv("FBSMI_WIDE_NOISE_FOLD"); return e ? atoi(e) : 1; }();
     const bool fold = fat && noise_fold && s->items == 1 && (s->debug_mask & 7) == 7;
     LgDev dz = d;

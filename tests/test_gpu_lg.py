@@ -132,6 +132,8 @@ WIDE_CASES = [
     (20, 20, 40000, 3, True),     # enough workgroups for k_lgw_gemm_fat (all row tiles per 32-slot workgroup)
     (33, 17, 35000, 2, False),    # ... with odd sizes and the stored path
     (100, 100, 12000, 2, True),   # ... at the reference's d = 100 (seven row tiles)
+    (100, 100, 3300, 2, True),    # just past the switch to k_lgw_gemm_fat (728 tiled workgroups), a partly filled last slot tile
+    (100, 100, 2500, 2, False),   # just below it (tiled kernel, stored path)
 ]
 
 
