@@ -26,8 +26,9 @@
 //   wide models, 16 < max(du, dv) <= 128           : row-major particles, drift on the f32 matrix cores
 //       (k_lgw_gemm: v_mfma_f32_16x16x4_f32 == ascending fmaf chain); N <= 256: one launch per step with the
 //       prologue fused in (noise and resampler uniforms drawn a step ahead by blocks of the previous launch); N > 256:
-//       norm -> cdf -> k_lgw_anc -> k_lgw_gemm | k_lgw_gemm_fat -> k_lgw_lse (large ensembles: the three small launches
-//       carry extra blocks that draw the step's noise)
+//       norm -> cdf -> k_lgw_anc -> k_lgw_gemm -> k_lgw_lse; from ~700 tiled workgroups per launch k_lgw_gemm_fat (one
+//       workgroup per slot tile walks all row tiles; the three small launches carry extra blocks that draw the step's
+//       noise; the log-density terms are summed in the kernel, through LDS) -> k_lg_lwpart
 //   N > 131072                                      : 4 / 16 slots per thread, four launches per step: norm -> cdf -> k_lg_heaps
 //       (compact bisection heaps) -> k_lg_propQ (lane-major slots, kill tests first, the killed sources' searches compacted
 //       through an LDS queue); chunks of a thread move as 16-byte accesses.  (The draws by a launch of their own, one
