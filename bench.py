@@ -620,22 +620,30 @@ def main():
             shard = sharded_leg(dev, dist, world, rank, args.sharded_steps)
         except Exception as e:  # every rank runs the same deterministic code: a failure is reported, the headline stays
             shard = {"error": f"{type(e).__name__}: {e}"}
+            print(f"[bench rank {rank}] sharded_c5 failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
     shard_lg = None
     if args.sharded_lg_steps > 0 and not args.no_single_chain:
         try:
             shard_lg = sharded_lg_leg(dev, dist, world, rank, args.sharded_lg_steps)
         except Exception as e:
             shard_lg = {"error": f"{type(e).__name__}: {e}"}
+            print(f"[bench rank {rank}] sharded_lg failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
     if rank == 0:
         out["sharded_c5"] = shard
         out["sharded_lg"] = shard_lg
     if dist is not None:
-        dist.barrier()
+        try:   # (a rank that failed inside a sharded leg may have left its peers in a collective: the line is printed regardless)
+            dist.barrier()
+        except Exception as e:
+            print(f"[bench rank {rank}] final barrier: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
     watchdog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

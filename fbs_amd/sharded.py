@@ -350,7 +350,10 @@ class ParticleShards:
         else:
             sp_host, ev = splits, None
         rowshape = tuple(us_local.shape[1:])
-        send = take_rows(us_local, send_rows.to(torch.int32)).reshape(send_rows.numel(), -1).contiguous()
+        rowsize = int(np.prod(rowshape, dtype=np.int64)) if rowshape else 1
+        # (explicit row size: a rank none of whose rows is anybody's ancestor -- a collapsed ensemble -- sends zero rows, and
+        # reshape(0, -1) is ambiguous)
+        send = take_rows(us_local, send_rows.to(torch.int32)).reshape(send_rows.numel(), rowsize).contiguous()
         send = self._h(send)
         if ev is not None:
             ev.synchronize()

@@ -124,6 +124,14 @@ def _worker(rank, world, port, N, T, q):
         got = shr.gather_ancestors(mine, A, lambda s, i: s[i.long()])
         ok_plan = ok_plan and torch.equal(got, us_full[A.long()][shr.offset:shr.offset + shr.count])
         ok_gather = ok_gather and torch.equal(shr.all_gather_rows(mine), us_full)
+    # a collapsed ensemble: every ancestor is one row of rank 0, so every other rank sends NOTHING (zero-row send buffers); and
+    # its mirror image, everything from the last rank
+    for a_all in (1, N - 1):
+        A = t(np.full(N, a_all, np.int32))
+        us_full = t(rng.normal(size=(N, 2, 3)).astype(np.float32))
+        mine = us_full[sh.offset:sh.offset + sh.count].clone()
+        got = sh.gather_ancestors(mine, A, lambda s, i: s[i.long()])
+        ok_plan = ok_plan and torch.equal(got, us_full[A.long()][sh.offset:sh.offset + sh.count])
 
     def transition_sampler(us_prev, v_prev, t_prev, key, row_slice=None):
         off, cnt, tot = row_slice
