@@ -264,8 +264,8 @@ class LGSweep:
             if sizes:
                 sz = [int(x) for x in sizes.split(",")]
                 if sum(sz) != self.C or any(x < 1 for x in sz):
-                    raise ValueError(f"FBSMI_CHAIN_GROUP_SIZES={sizes} does not cover {self.C} chains")
-            else:
+                    sz = None          # (the variable is process-wide: batches of another size keep the default policy)
+            if sz is None:
                 G = int(os.environ.get("FBSMI_CHAIN_GROUPS", "0"))
                 if G < 1:
                     if wide:
