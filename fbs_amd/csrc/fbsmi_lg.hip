@@ -2851,6 +2851,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
         // compiler rotates the read to the top of the next iteration and waits for it there)
         if (kWideTile * tr + 16 * ar < D) {   // (the upper half of the last row tile can lie wholly outside the matrix: D = 200 ends
             const int nq = Q >> 2;            // at row 8 of tile 6, whose waves with ar = 1 have nothing to multiply)
+            __builtin_amdgcn_s_setprio(3);   // the product loop ahead of other waves' staging / epilogue code
             float4 a0 = ga[0], b0 = zb[0];
 #pragma unroll 1
             for (int q4 = 0; q4 < nq; q4 += 2) {
@@ -2874,6 +2875,7 @@ __global__ void __launch_bounds__(kBlock) k_lgw_gemm_fat(LgDev dd, int s, int nr
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (tr == 0) { FBSMI_STAMP(22) }
         if (tr == 5) { FBSMI_STAMP(26) }
         if (mo < N && vec4) {
